@@ -1,0 +1,129 @@
+/* vtc_amd.h -- C ABI of the MI355X-native VTC hot path (libvtc_amd.so, gfx950).
+ *
+ * The reference (danieldager/VTC) has no FFI: its boundary for this path is the Python import
+ * surface of the third-party package `segma` (src/pipeline/vtc.py:41-47, src/core/intervals.py:10).
+ * Each entry point below names the segma call (and the reference call site) it stands behind;
+ * vtc_amd/segma_compat/ is the Python side that binds them with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * vtc_status; vtc_last_error() gives the message.  `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Device pointers are marked [dev], host pointers [host].
+ * The library never takes ownership of caller memory.  One vtc_model is bound to one GPU and is not
+ * thread-safe; use one model per worker (the reference runs one process per GPU, slurm/vtc.slurm:9-10).
+ */
+#ifndef VTC_AMD_H
+#define VTC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTC_ABI_VERSION 1
+#define VTC_MAX_LABELS 8
+#define VTC_N_LAYERS 12
+
+typedef enum {
+  VTC_OK = 0,
+  VTC_ERR_ARG = -1,       /* bad argument / unsupported spec */
+  VTC_ERR_HIP = -2,       /* a HIP runtime call failed */
+  VTC_ERR_NO_GPU = -3,    /* no gfx950 device visible */
+  VTC_ERR_CAPACITY = -4,  /* caller buffer too small; the needed size is reported */
+  VTC_ERR_SHORT = -5      /* audio shorter than the 400-sample receptive field */
+} vtc_status;
+
+typedef struct vtc_model vtc_model; /* opaque */
+
+/* Model geometry that segma reads from its YAML config (cfg.audio.chunk_duration_s, cfg.data.classes;
+ * src/pipeline/vtc.py:183-195).  The conv stack is the fixed HuBERT-base geometry named at
+ * src/analysis/chunk_artifact.py:43-48 (kernels 10,3,3,3,3,2,2; strides 5,2,2,2,2,2,2). */
+typedef struct {
+  int32_t abi_version;    /* VTC_ABI_VERSION */
+  int32_t n_labels;       /* 1..VTC_MAX_LABELS */
+  int32_t window_samples; /* chunk_duration_s * 16000; 400 <= .. <= 164239 (T <= 512 frames) */
+  int32_t max_batch;      /* windows per forward pass (segma's batch_size) */
+  int32_t mfma_dtype;     /* 0 = bf16 operands, 1 = f16 operands (fp32 accumulate either way) */
+  int32_t reserved[3];
+} vtc_spec;
+
+/* fp32 host tensors in PyTorch-canonical layouts (names: HF HubertModel state dict). */
+typedef struct {
+  const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b; /* [768,768], [768] */
+  const float *ln1_w, *ln1_b;                                 /* [768] */
+  const float *ff1_w, *ff1_b;                                 /* [3072,768], [3072] */
+  const float *ff2_w, *ff2_b;                                 /* [768,3072], [768] */
+  const float *ln2_w, *ln2_b;                                 /* [768] */
+} vtc_layer_weights;
+
+typedef struct {
+  const float* conv_w[7];  /* [512,1,10], [512,512,3] x4, [512,512,2] x2 (no bias) */
+  const float *gn_w, *gn_b;       /* GroupNorm(512 groups) affine, [512] */
+  const float *fp_ln_w, *fp_ln_b; /* feature-projection LayerNorm, [512] */
+  const float *fp_w, *fp_b;       /* projection [768,512], [768] */
+  const float* pos_w;             /* positional conv weight with weight-norm already folded, [768,48,128] */
+  const float* pos_b;             /* [768] */
+  const float *enc_ln_w, *enc_ln_b; /* [768] */
+  vtc_layer_weights layer[VTC_N_LAYERS];
+  const float *head_w, *head_b;   /* per-frame multi-label head [n_labels,768], [n_labels] */
+} vtc_weights;
+
+/* Stands behind: Models[name].load_from_checkpoint(...).eval().to(device)  (vtc.py:185-192).
+ * Packs the weights for the MFMA kernels, uploads them and allocates the activation workspace. */
+int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model** out);
+void vtc_destroy(vtc_model* m);
+/* Message of the last failure on `m` (or of the last failed vtc_create when m == NULL). */
+const char* vtc_last_error(const vtc_model* m);
+
+/* Stands behind: model.conv_settings (vtc.py:194) -- frames per window T, and the frame count of a file. */
+int vtc_frames_per_window(const vtc_model* m);
+int64_t vtc_frames_for_samples(int64_t n_samples);
+
+/* Stands behind: the batched model.forward inside segma.inference.apply_model_on_audio.
+ * Runs n_windows (<= max_batch) windows.  Window i reads window_samples samples from
+ * wav[start[i] ...], of which only the first valid[i] are real (the rest count as zeros), and writes
+ * the logits of its first keep[i] frames to logits[(dst_row[i] + t) * n_labels + l].
+ * Asynchronous on `stream`; the four index arrays are copied before the call returns. */
+int vtc_forward_windows(vtc_model* m, const float* wav /*[dev]*/, const int64_t* start /*[host]*/,
+                        const int32_t* valid /*[host]*/, const int64_t* dst_row /*[host]*/,
+                        const int32_t* keep /*[host]*/, int32_t n_windows, float* logits /*[dev]*/, void* stream);
+
+/* Stands behind: segma.inference.apply_model_on_audio after decoding (vtc.py:236-243): tiles one
+ * waveform of n_samples into windows stepped by T*320 samples (chunk_artifact.py:71-73), runs them in
+ * batches of `batch` and leaves the stitched logits [n_frames][n_labels] in `logits`
+ * (capacity vtc_frames_for_samples(n_samples) rows).  Asynchronous on `stream`. */
+int vtc_infer_waveform(vtc_model* m, const float* wav /*[dev]*/, int64_t n_samples, int32_t batch,
+                       float* logits /*[dev]*/, int64_t* n_frames /*[host]*/, void* stream);
+
+/* Stands behind: segma.inference.apply_thresholds + create_intervals (vtc.py:84-91) and the sigmoid
+ * summary (vtc.py:266-273).  Frame f of label l is active iff lo_logit[l] <= logits[f][l] <= hi_logit[l].
+ * Every run of active frames i..j yields out_start = i*320, out_end = j*320+400 (samples), out_label = l;
+ * output is label-major, time-ordered.  Synchronises `stream` before returning.
+ * On VTC_ERR_CAPACITY *n_out holds the number of intervals needed. */
+int vtc_decode(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,
+               const float* hi_logit /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,
+               int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
+               void* stream);
+
+/* Test hook: copy an intermediate activation of the LAST vtc_forward_windows call to the host as fp32.
+ * stage: 0..6 conv layer outputs (B,L_i,512); 7 projection (B*T,768); 8 encoder input after pos-conv+LN;
+ * 9+l output of transformer layer l.  Returns the element count, or a negative status. */
+int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t n_windows, float* out /*[host]*/, int64_t cap);
+/* Test hook: make the next vtc_forward_windows calls return right after `stage` (-1 = run everything),
+ * so that vtc_debug_stage reads that stage before later stages reuse its buffer. */
+int vtc_debug_stop_after(vtc_model* m, int32_t stage);
+
+/* Per-kernel-class timing with HIP events on the launch stream (bench.py roofline object).
+ * vtc_profile_enable(m,1) starts recording every launch; vtc_profile_read synchronises, sums the
+ * recorded launches per class and resets.  Classes: see vtc_profile_class_name. */
+#define VTC_PROF_CLASSES 8
+int vtc_profile_enable(vtc_model* m, int32_t on);
+int vtc_profile_read(vtc_model* m, double* ms /*[VTC_PROF_CLASSES]*/, int64_t* launches /*[VTC_PROF_CLASSES]*/,
+                     double* flops /*[VTC_PROF_CLASSES]*/, double* bytes /*[VTC_PROF_CLASSES]*/);
+const char* vtc_profile_class_name(int32_t cls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTC_AMD_H */

@@ -1,0 +1,139 @@
+// Threshold -> run-length decoding of stitched logits, on the GPU.
+// Replaces segma.inference.apply_thresholds + create_intervals (call sites
+// /root/reference/src/pipeline/vtc.py:84-91) and the sigmoid summary (vtc.py:266-273).
+// A frame of label j is active iff lo[j] <= logit <= hi[j] (bounds already mapped to logit space by
+// the host, see vtc_amd/segma_compat/inference.py); a run of active frames i..j becomes
+// (i*320, j*320+400) samples (src/analysis/chunk_artifact.py:11-13,75-83) on the host side.
+// Three passes, deterministic: count run starts/ends per 256-frame block, exclusive scan, emit.
+#pragma once
+#include "common.cuh"
+
+namespace vtc {
+
+constexpr int kMaxLabels = 8;
+
+struct DecodeParams {
+  const float* logits;  // [n][nl]
+  long long n;
+  int nl;
+  int nblk;
+  float lo[kMaxLabels];
+  float hi[kMaxLabels];
+};
+
+__device__ __forceinline__ bool frame_active(const DecodeParams& p, long long f, int l) {
+  if (f < 0 || f >= p.n) return false;
+  const float x = p.logits[f * p.nl + l];
+  return x >= p.lo[l] && x <= p.hi[l];
+}
+
+// counts: [2][nl][nblk] (0 = starts, 1 = ends); sig_sum[nblk] (fp64), max_logit[nblk]
+__global__ __launch_bounds__(256) void decode_count_kernel(DecodeParams p, int* __restrict__ counts,
+                                                           double* __restrict__ sig_sum, float* __restrict__ max_logit) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  double ssum = 0.0;
+  float mx = -INFINITY;
+  for (int l = 0; l < p.nl; ++l) {
+    const bool a = frame_active(p, f, l);
+    const bool st = a && !frame_active(p, f - 1, l);
+    const bool en = a && !frame_active(p, f + 1, l);
+    const int cs = __syncthreads_count(st);
+    const int ce = __syncthreads_count(en);
+    if (threadIdx.x == 0) {
+      counts[(0 * p.nl + l) * p.nblk + blockIdx.x] = cs;
+      counts[(1 * p.nl + l) * p.nblk + blockIdx.x] = ce;
+    }
+    if (f < p.n) {
+      const float x = p.logits[f * p.nl + l];
+      ssum += (double)(1.f / (1.f + __expf(-x)));
+      mx = fmaxf(mx, x);
+    }
+  }
+  __shared__ double rs[4];
+  __shared__ float rm[4];
+  ssum = wave_sum_d(ssum);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = ssum; rm[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sig_sum[blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    max_logit[blockIdx.x] = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+  }
+}
+
+// One block per (kind,label) row of counts: in-place exclusive scan, total -> totals[row].
+// Block 0 additionally folds the sigmoid partials (fixed order) into summary[0..1].
+__global__ __launch_bounds__(1024) void decode_scan_kernel(int* __restrict__ counts, int nblk, int* __restrict__ totals,
+                                                           const double* __restrict__ sig_sum,
+                                                           const float* __restrict__ max_logit,
+                                                           double* __restrict__ summary) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  int* row = counts + (long long)blockIdx.x * nblk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? row[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int carry = carry_s;
+    if (i < nblk) row[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    float mx = -INFINITY;
+    for (int i = 0; i < nblk; ++i) { s += sig_sum[i]; mx = fmaxf(mx, max_logit[i]); }
+    summary[0] = s;
+    summary[1] = (double)mx;
+  }
+}
+
+__device__ __forceinline__ int block_rank(bool pred, int* wcnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(pred);
+  const int r = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += wcnt[w];
+  __syncthreads();
+  return off + r;
+}
+
+// out_start / out_end: [nl][cap] frame indices, k-th start pairs with k-th end of the same label.
+__global__ __launch_bounds__(256) void decode_emit_kernel(DecodeParams p, const int* __restrict__ offsets, long long cap,
+                                                          int* __restrict__ out_start, int* __restrict__ out_end) {
+  __shared__ int wcnt[4];
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (int l = 0; l < p.nl; ++l) {
+    const bool a = frame_active(p, f, l);
+    const bool st = a && !frame_active(p, f - 1, l);
+    const bool en = a && !frame_active(p, f + 1, l);
+    const int rs = block_rank(st, wcnt);
+    const int re = block_rank(en, wcnt);
+    if (st) {
+      const long long k = offsets[(0 * p.nl + l) * p.nblk + blockIdx.x] + rs;
+      if (k < cap) out_start[l * cap + k] = (int)f;
+    }
+    if (en) {
+      const long long k = offsets[(1 * p.nl + l) * p.nblk + blockIdx.x] + re;
+      if (k < cap) out_end[l * cap + k] = (int)f;
+    }
+  }
+}
+
+}  // namespace vtc

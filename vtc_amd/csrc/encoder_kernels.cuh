@@ -1,0 +1,263 @@
+// Bandwidth-bound kernels of the BabyHuBERT encoder: conv layer 0 + GroupNorm + GELU, LayerNorm
+// (+ fused per-frame multi-label head), positional-conv input packing.
+// Arithmetic follows HF modeling_hubert.py:154-175 (conv0/GroupNorm/GELU), :216-231 (projection LN),
+// :439-441 (encoder LN), :387-397 (post-LN layers); the reference names this stack at
+// src/analysis/chunk_artifact.py:40-48.
+#pragma once
+#include "common.cuh"
+
+namespace vtc {
+
+struct WindowTable {          // device arrays, one entry per window of the batch
+  const long long* start;     // first sample of the window in the waveform arena
+  const int* valid;           // real samples available (the rest of the window is zero padding)
+  const long long* dst_row;   // first output row (global frame index) of the window
+  const int* keep;            // frames kept from the window (<= T)
+};
+
+// ---------------------------------------------------------------------------------------------
+// conv0 statistics.  conv0 is linear without bias, y[c,t] = sum_j w[c,j] x[5t+j], so the GroupNorm
+// statistics of every channel follow from 10 first moments S_j = sum_t x[5t+j] and 55 second moments
+// R[j,j'] = sum_t x[5t+j] x[5t+j'] of the window -- 65 numbers instead of 512 x L0 conv outputs.
+// Accumulated in fp64, per-block partials summed in a fixed order (bitwise reproducible).
+// ---------------------------------------------------------------------------------------------
+constexpr int kStatN = 65;
+constexpr int kStatChunk = 2048;  // conv0 frames per block
+
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
+                                                            double* __restrict__ partial /*[B][nchunk][65]*/) {
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const long long s0 = wt.start[b];
+  const int valid = wt.valid[b];
+  double acc[kStatN];
+#pragma unroll
+  for (int i = 0; i < kStatN; ++i) acc[i] = 0.0;
+  const int t_end = min(L0, (chunk + 1) * kStatChunk);
+  for (int t = chunk * kStatChunk + threadIdx.x; t < t_end; t += 256) {
+    double x[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int i = 5 * t + j;
+      x[j] = i < valid ? (double)wav[s0 + i] : 0.0;
+    }
+    int k = 10;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      acc[j] += x[j];
+#pragma unroll
+      for (int j2 = j; j2 < 10; ++j2) { acc[k] = fma(x[j], x[j2], acc[k]); ++k; }
+    }
+  }
+  __shared__ double red[4][kStatN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kStatN; ++i) {
+    const double v = wave_sum_d(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kStatN) {
+    const int i = threadIdx.x;
+    partial[((long long)b * nchunk + chunk) * kStatN + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+// One block per window, one thread per channel: fold the moments with the channel's 10 taps.
+__global__ __launch_bounds__(512) void conv0_gn_finalize_kernel(const double* __restrict__ partial, int nchunk, int L0,
+                                                                const float* __restrict__ w0 /*[512][10]*/,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ scale /*[B][512]*/,
+                                                                float* __restrict__ shift) {
+  __shared__ double mom[kStatN];
+  const int b = blockIdx.x;
+  if (threadIdx.x < kStatN) {
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += partial[((long long)b * nchunk + c) * kStatN + threadIdx.x];
+    mom[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  double w[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w[j] = (double)w0[c * 10 + j];
+  double s1 = 0.0, s2 = 0.0;
+  int k = 10;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    s1 += w[j] * mom[j];
+#pragma unroll
+    for (int j2 = j; j2 < 10; ++j2) {
+      const double r = w[j] * w[j2] * mom[k++];
+      s2 += (j2 == j) ? r : 2.0 * r;
+    }
+  }
+  const double mean = s1 / L0;
+  double var = s2 / L0 - mean * mean;   // biased variance, as GroupNorm
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + 1e-5);
+  const double sc = (double)gamma[c] * rstd;
+  scale[b * 512 + c] = (float)sc;
+  shift[b * 512 + c] = (float)((double)beta[c] - mean * sc);
+}
+
+// conv0 + GroupNorm affine + GELU -> channel-last (B, L0, 512) 16-bit.  Waveform tile staged in LDS,
+// each lane owns 8 adjacent channels (taps in registers) so a wave stores one 1 KiB frame row.
+constexpr int kC0Frames = 64;  // conv0 frames per block
+
+template <bool F16>
+__global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
+                                                          const float* __restrict__ w0, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, h16* __restrict__ out) {
+  __shared__ float xs[5 * kC0Frames + 8];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kC0Frames;
+  const long long s0 = wt.start[b];
+  const int valid = wt.valid[b];
+  for (int i = threadIdx.x; i < 5 * kC0Frames + 5; i += 256) {
+    const int g = 5 * t0 + i;
+    xs[i] = g < valid ? wav[s0 + g] : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * 8;
+  float w[8][10], sc[8], sh[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[c][j] = w0[(c0 + c) * 10 + j];
+    sc[c] = scale[b * 512 + c0 + c];
+    sh[c] = shift[b * 512 + c0 + c];
+  }
+  __syncthreads();
+  for (int f = wave; f < kC0Frames; f += 4) {
+    const int t = t0 + f;
+    if (t >= L0) break;
+    float x[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) x[j] = xs[5 * f + j];
+    unsigned pk[4];
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+      float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        y0 = fmaf(w[c][j], x[j], y0);
+        y1 = fmaf(w[c + 1][j], x[j], y1);
+      }
+      y0 = gelu_f(fmaf(y0, sc[c], sh[c]));
+      y1 = gelu_f(fmaf(y1, sc[c + 1], sh[c + 1]));
+      pk[c >> 1] = pack2<F16>(y0, y1);
+    }
+    *(uint4*)(out + ((long long)b * L0 + t) * 512 + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over rows; one wave per row, two-pass (mean, then centred variance) in registers.
+//   D = 512: 16-bit input (conv6 output), 16-bit output.
+//   D = 768: fp32 input, fp32 + 16-bit outputs; HEAD fuses the per-frame multi-label head
+//            (n_labels linear units on the normalised row, fp32) and writes stitched logits.
+// ---------------------------------------------------------------------------------------------
+struct HeadParams {
+  const float* w;   // [n_labels][768]
+  const float* b;   // [n_labels]
+  float* logits;    // [total_rows][n_labels]
+  int n_labels;
+  int T;            // frames per window
+  WindowTable wt;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256) void layernorm512_kernel(const h16* __restrict__ in, const float* __restrict__ g,
+                                                           const float* __restrict__ bt, h16* __restrict__ out, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const u16x8 raw = *(const u16x8*)(in + (long long)row * 512 + lane * 8);
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = from_h16<F16>(raw[i]); s += v[i]; }
+  const float mean = wave_sum(s) * (1.f / 512.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / 512.f) + 1e-5f);
+  const float4 g0 = *(const float4*)(g + lane * 8), g1 = *(const float4*)(g + lane * 8 + 4);
+  const float4 b0 = *(const float4*)(bt + lane * 8), b1 = *(const float4*)(bt + lane * 8 + 4);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  unsigned pk[4];
+#pragma unroll
+  for (int i = 0; i < 8; i += 2)
+    pk[i >> 1] = pack2<F16>(fmaf(v[i] * rstd, gg[i], bb[i]), fmaf(v[i + 1] * rstd, gg[i + 1], bb[i + 1]));
+  *(uint4*)(out + (long long)row * 512 + lane * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+template <bool F16, bool HEAD>
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ in, const float* __restrict__ g,
+                                                           const float* __restrict__ bt, float* __restrict__ out32,
+                                                           h16* __restrict__ out16, int rows, HeadParams hp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* src = in + (long long)row * 768;
+  float v[12];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 x = *(const float4*)(src + i * 256 + lane * 4);
+    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+    s += (x.x + x.y) + (x.z + x.w);
+  }
+  const float mean = wave_sum(s) * (1.f / 768.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(bt + c);
+    v[4 * i] = fmaf(v[4 * i] * rstd, gg.x, bb.x);
+    v[4 * i + 1] = fmaf(v[4 * i + 1] * rstd, gg.y, bb.y);
+    v[4 * i + 2] = fmaf(v[4 * i + 2] * rstd, gg.z, bb.z);
+    v[4 * i + 3] = fmaf(v[4 * i + 3] * rstd, gg.w, bb.w);
+    *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    *(uint2*)(out16 + (long long)row * 768 + c) =
+        make_uint2(pack2<F16>(v[4 * i], v[4 * i + 1]), pack2<F16>(v[4 * i + 2], v[4 * i + 3]));
+  }
+  if constexpr (HEAD) {
+    const int b = row / hp.T, t = row - b * hp.T;
+    const bool keep = t < hp.wt.keep[b];
+    const long long dst = hp.wt.dst_row[b] + t;
+    for (int l = 0; l < hp.n_labels; ++l) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float4 ww = *(const float4*)(hp.w + l * 768 + i * 256 + lane * 4);
+        d = fmaf(v[4 * i], ww.x, d); d = fmaf(v[4 * i + 1], ww.y, d);
+        d = fmaf(v[4 * i + 2], ww.z, d); d = fmaf(v[4 * i + 3], ww.w, d);
+      }
+      d = wave_sum(d);
+      if (lane == 0 && keep) hp.logits[dst * hp.n_labels + l] = d + hp.b[l];
+    }
+  }
+}
+
+// Positional-conv input: fp32 (B*T, 768) -> zero-padded group-major 16-bit (B, 16, T+128, 48) so the
+// k=128 window of output frame t is the contiguous slice rows [t, t+128) (pad 64 front, modeling_hubert.py:48-54).
+template <bool F16>
+__global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ h0, h16* __restrict__ out, int T) {
+  const int p = blockIdx.x, b = blockIdx.y;
+  const int TP = T + 128;
+  const int t = p - 64;
+  const bool live = t >= 0 && t < T;
+  for (int c = threadIdx.x; c < 768; c += 256) {
+    const int g = c / 48, ci = c - g * 48;
+    const float v = live ? h0[((long long)b * T + t) * 768 + c] : 0.f;
+    out[(((long long)b * 16 + g) * TP + p) * 48 + ci] = to_h16<F16>(v);
+  }
+}
+
+}  // namespace vtc

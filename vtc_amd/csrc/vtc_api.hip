@@ -1,0 +1,624 @@
+// libvtc_amd.so -- C ABI (include/vtc_amd.h) over the hand-written gfx950 kernels.
+// Host side: weight packing, workspace, launch sequence of one BabyHuBERT forward, decode.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vtc_amd.h"
+#include "attention.cuh"
+#include "common.cuh"
+#include "decode_kernels.cuh"
+#include "encoder_kernels.cuh"
+#include "gemm.cuh"
+
+using namespace vtc;
+
+namespace {
+
+constexpr int kKernels[7] = {10, 3, 3, 3, 3, 2, 2};  // src/analysis/chunk_artifact.py:43
+constexpr int kStrides[7] = {5, 2, 2, 2, 2, 2, 2};   // src/analysis/chunk_artifact.py:44
+constexpr int kSlots = 8;
+
+enum ProfClass { PC_CONV0_STATS = 0, PC_CONV0_APPLY, PC_GEMM, PC_ATTN, PC_LAYERNORM, PC_PACK, PC_DECODE, PC_OTHER };
+const char* kProfNames[VTC_PROF_CLASSES] = {"conv0_stats", "conv0_apply", "gemm_mfma", "attention",
+                                            "layernorm_head", "posconv_pack", "decode", "other"};
+
+thread_local std::string g_create_error;
+
+struct LayerDev {
+  h16 *qkv_w, *o_w, *ff1_w, *ff2_w;
+  float *qkv_b, *o_b, *ff1_b, *ff2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct vtc_model {
+  vtc_spec spec{};
+  int device = 0;
+  bool f16 = false;
+  int T = 0;
+  int L[7] = {0};
+  std::string err;
+  std::vector<void*> allocs;
+
+  // weights
+  float *conv0_w = nullptr, *gn_w = nullptr, *gn_b = nullptr, *fp_ln_w = nullptr, *fp_ln_b = nullptr, *fp_b = nullptr;
+  float *pos_b = nullptr, *enc_ln_w = nullptr, *enc_ln_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+  h16* conv_w[7] = {nullptr};
+  h16 *fp_w = nullptr, *pos_w = nullptr;
+  LayerDev layer[VTC_N_LAYERS]{};
+
+  // workspace
+  h16 *actA = nullptr, *actB = nullptr, *x16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffn16 = nullptr, *posin = nullptr;
+  float *h0 = nullptr, *tmp32 = nullptr, *x32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+  double* mom_partial = nullptr;
+  int nchunk = 0;
+
+  // window table: device copy + pinned staging ring
+  long long *d_start = nullptr, *d_dst = nullptr;
+  int *d_valid = nullptr, *d_keep = nullptr;
+  char* h_stage = nullptr;
+  hipEvent_t slot_ev[kSlots]{};
+  bool slot_used[kSlots] = {false};
+  int slot = 0;
+
+  // decode scratch (grown on demand)
+  long long dec_frames_cap = 0;
+  int *dec_counts = nullptr, *dec_totals = nullptr, *dec_start = nullptr, *dec_end = nullptr;
+  double *dec_sig = nullptr, *dec_summary = nullptr;
+  float* dec_max = nullptr;
+
+  int debug_stop = -1;
+
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_next = 0;
+};
+
+namespace {
+
+int fail(vtc_model* m, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(m, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail((m), VTC_ERR_HIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+unsigned short host_to_h16(float x, bool f16) {
+  if (f16) {
+    _Float16 h = (_Float16)x;  // round-to-nearest-even
+    unsigned short r;
+    memcpy(&r, &h, 2);
+    return r;
+  }
+  unsigned u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T>
+int dev_alloc(vtc_model* m, T** p, size_t n) {
+  void* q = nullptr;
+  HIP_TRY(m, hipMalloc(&q, n * sizeof(T) + 256));
+  m->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+int upload_f32(vtc_model* m, float** dst, const float* src, size_t n) {
+  if (!src) return fail(m, VTC_ERR_ARG, "missing weight tensor");
+  if (int rc = dev_alloc(m, dst, n)) return rc;
+  HIP_TRY(m, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int upload_h16(vtc_model* m, h16** dst, const std::vector<unsigned short>& v) {
+  if (int rc = dev_alloc(m, dst, v.size())) return rc;
+  HIP_TRY(m, hipMemcpy(*dst, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// plain [N][K] fp32 -> 16 bit, optional row scale for rows [0, scale_rows)
+std::vector<unsigned short> pack_linear(const float* w, int N, int K, bool f16, float scale = 1.f, int scale_rows = 0) {
+  std::vector<unsigned short> v((size_t)N * K);
+  for (int n = 0; n < N; ++n) {
+    const float s = n < scale_rows ? scale : 1.f;
+    for (int k = 0; k < K; ++k) v[(size_t)n * K + k] = host_to_h16(w[(size_t)n * K + k] * s, f16);
+  }
+  return v;
+}
+
+// conv weight [N][Cin][k] -> [N][j*Cin + ci] (the im2col order of channel-last activations)
+std::vector<unsigned short> pack_conv(const float* w, int N, int Cin, int k, bool f16) {
+  std::vector<unsigned short> v((size_t)N * Cin * k);
+  for (int n = 0; n < N; ++n)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int j = 0; j < k; ++j)
+        v[((size_t)n * k + j) * Cin + ci] = host_to_h16(w[((size_t)n * Cin + ci) * k + j], f16);
+  return v;
+}
+
+// grouped positional conv [768][48][128] -> [16 groups][64 rows (48 real + 16 zero)][j*48 + ci]
+std::vector<unsigned short> pack_posconv(const float* w, bool f16) {
+  std::vector<unsigned short> v((size_t)16 * 64 * 6144, 0);
+  for (int g = 0; g < 16; ++g)
+    for (int co = 0; co < 48; ++co)
+      for (int ci = 0; ci < 48; ++ci)
+        for (int j = 0; j < 128; ++j)
+          v[((size_t)(g * 64 + co)) * 6144 + j * 48 + ci] = host_to_h16(w[((size_t)(g * 48 + co) * 48 + ci) * 128 + j], f16);
+  return v;
+}
+
+// ------------------------------------------------------------------ profiling
+void prof_begin(vtc_model* m, int cls, double flops, double bytes, hipStream_t s) {
+  if (!m->prof_on) return;
+  if (m->ev_next == m->ev_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { m->prof_on = false; return; }
+    m->ev_pool.push_back({a, b});
+  }
+  auto& ev = m->ev_pool[m->ev_next++];
+  m->prof.push_back({cls, flops, bytes, ev.first, ev.second});
+  (void)hipEventRecord(ev.first, s);
+}
+void prof_end(vtc_model* m, hipStream_t s) {
+  if (!m->prof_on || m->prof.empty()) return;
+  (void)hipEventRecord(m->prof.back().e1, s);
+}
+#define LAUNCH(m, cls, flops, bytes, s, ...) \
+  do { prof_begin((m), (cls), (flops), (bytes), (s)); __VA_ARGS__; prof_end((m), (s)); } while (0)
+
+// ------------------------------------------------------------------ GEMM dispatch
+template <bool F16, int BN, int EPI>
+void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
+  const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
+  LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
+}
+
+GemmParams plain(const h16* A, const h16* W, void* C, const float* bias, const float* resid, int M, int N, int K) {
+  GemmParams p{};
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.resid = resid;
+  p.M = M; p.N = N; p.K = K; p.ldc = N;
+  p.rows_per_batch = M; p.a_row_stride = K; p.a_batch_stride = 0;
+  return p;
+}
+
+template <bool F16>
+int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStream_t s) {
+  const int T = m->T;
+  const int* L = m->L;
+  WindowTable wt{m->d_start, m->d_valid, m->d_dst, m->d_keep};
+
+  // ---- conv0: GroupNorm statistics from window moments, then conv + affine + GELU
+  LAUNCH(m, PC_CONV0_STATS, 0.0, (double)nw * m->spec.window_samples * 4, s, {
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3(m->nchunk, nw), dim3(256), 0, s, wav, wt, L[0], m->mom_partial);
+    hipLaunchKernelGGL(conv0_gn_finalize_kernel, dim3(nw), dim3(512), 0, s, m->mom_partial, m->nchunk, L[0], m->conv0_w,
+                       m->gn_w, m->gn_b, m->gn_scale, m->gn_shift);
+  });
+  LAUNCH(m, PC_CONV0_APPLY, 0.0, (double)nw * (m->spec.window_samples * 4.0 + (double)L[0] * 512 * 2), s,
+         hipLaunchKernelGGL((conv0_apply_kernel<F16>), dim3((L[0] + kC0Frames - 1) / kC0Frames, nw), dim3(256), 0, s, wav,
+                            wt, L[0], m->conv0_w, m->gn_scale, m->gn_shift, m->actA));
+  if (m->debug_stop == 0) return 0;
+
+  // ---- conv 1..6 as implicit GEMM over channel-last activations, GELU fused
+  h16* src = m->actA;
+  h16* dst = m->actB;
+  for (int i = 1; i < 7; ++i) {
+    GemmParams p{};
+    p.A = src; p.W = m->conv_w[i]; p.C = dst;
+    p.M = nw * L[i]; p.N = 512; p.K = kKernels[i] * 512; p.ldc = 512;
+    p.rows_per_batch = L[i];
+    p.a_row_stride = (long long)kStrides[i] * 512;
+    p.a_batch_stride = (long long)L[i - 1] * 512;
+    gemm_go<F16, 128, EPI_GELU>(m, p, 1, s);
+    std::swap(src, dst);
+    if (m->debug_stop == i) return 0;
+  }
+  // src = conv6 output (nw*T, 512); dst is free
+  const int M = nw * T;
+  LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 512 * 4, s,
+         hipLaunchKernelGGL((layernorm512_kernel<F16>), dim3((M + 3) / 4), dim3(256), 0, s, src, m->fp_ln_w, m->fp_ln_b, dst, M));
+  gemm_go<F16, 128, EPI_BIAS | EPI_F32>(m, plain(dst, m->fp_w, m->h0, m->fp_b, nullptr, M, 768, 512), 1, s);
+  if (m->debug_stop == 7) return 0;
+
+  // ---- positional conv (16 groups x [T x 6144] x [6144 x 48]) + GELU + residual, then LayerNorm
+  LAUNCH(m, PC_PACK, 0.0, (double)M * 768 * 6, s,
+         hipLaunchKernelGGL((posconv_pack_kernel<F16>), dim3(T + 128, nw), dim3(256), 0, s, m->h0, m->posin, T));
+  {
+    GemmParams p{};
+    p.A = m->posin; p.W = m->pos_w; p.C = m->tmp32; p.bias = m->pos_b; p.resid = m->h0;
+    p.M = M; p.N = 48; p.K = 6144; p.ldc = 768;
+    p.rows_per_batch = T; p.a_row_stride = 48; p.a_batch_stride = (long long)16 * (T + 128) * 48;
+    p.a_z_stride = (long long)(T + 128) * 48; p.w_z_stride = (long long)64 * 6144; p.c_col_z = 48;
+    gemm_go<F16, 64, EPI_BIAS | EPI_GELU | EPI_RESID | EPI_F32>(m, p, 16, s);
+  }
+  HeadParams nohead{};
+  LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
+         hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, m->enc_ln_w,
+                            m->enc_ln_b, m->x32, m->x16, M, nohead));
+  if (m->debug_stop == 8) return 0;
+
+  // ---- 12 post-LN transformer layers
+  const int nkt = (T + 31) / 32;
+  const size_t attn_lds = (size_t)nkt * 32 * 128 * 2;
+  const double attn_flops = 4.0 * (double)nw * 12 * (double)T * T * 64;
+  for (int l = 0; l < VTC_N_LAYERS; ++l) {
+    const LayerDev& w = m->layer[l];
+    gemm_go<F16, 128, EPI_BIAS>(m, plain(m->x16, w.qkv_w, m->qkv16, w.qkv_b, nullptr, M, 2304, 768), 1, s);
+    LAUNCH(m, PC_ATTN, attn_flops, 0.0, s,
+           hipLaunchKernelGGL((attention_kernel<F16>), dim3((nkt + kAttnWaves - 1) / kAttnWaves, nw * 12), dim3(512),
+                              attn_lds, s, m->qkv16, m->ctx16, T, nkt));
+    gemm_go<F16, 128, EPI_BIAS | EPI_RESID | EPI_F32>(m, plain(m->ctx16, w.o_w, m->tmp32, w.o_b, m->x32, M, 768, 768), 1, s);
+    LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
+           hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln1_w,
+                              w.ln1_b, m->x32, m->x16, M, nohead));
+    gemm_go<F16, 128, EPI_BIAS | EPI_GELU>(m, plain(m->x16, w.ff1_w, m->ffn16, w.ff1_b, nullptr, M, 3072, 768), 1, s);
+    gemm_go<F16, 128, EPI_BIAS | EPI_RESID | EPI_F32>(m, plain(m->ffn16, w.ff2_w, m->tmp32, w.ff2_b, m->x32, M, 768, 3072), 1, s);
+    const bool last = l == VTC_N_LAYERS - 1;
+    if (!last || m->debug_stop == 9 + l) {
+      LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
+             hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
+                                w.ln2_b, m->x32, m->x16, M, nohead));
+    } else {
+      // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
+      HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
+      LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
+             hipLaunchKernelGGL((layernorm768_kernel<F16, true>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
+                                w.ln2_b, m->x32, m->x16, M, hp));
+    }
+    if (m->debug_stop == 9 + l) return 0;
+  }
+  return 0;
+}
+
+int ensure_decode_scratch(vtc_model* m, long long n) {
+  if (n <= m->dec_frames_cap) return 0;
+  for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
+                  (void*)m->dec_summary, (void*)m->dec_max})
+    if (p) (void)hipFree(p);
+  m->dec_frames_cap = 0;
+  const long long cap = n + n / 4 + 1024;
+  const long long nblk = (cap + 255) / 256;
+  const int nl = m->spec.n_labels;
+  HIP_TRY(m, hipMalloc((void**)&m->dec_counts, sizeof(int) * 2 * nl * nblk));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_totals, sizeof(int) * 2 * VTC_MAX_LABELS));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_start, sizeof(int) * nl * (cap / 2 + 1)));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_end, sizeof(int) * nl * (cap / 2 + 1)));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_sig, sizeof(double) * nblk));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_summary, sizeof(double) * 2));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_max, sizeof(float) * nblk));
+  m->dec_frames_cap = cap;
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* vtc_last_error(const vtc_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int64_t vtc_frames_for_samples(int64_t n) { return n < kRfSize ? 0 : (n - kRfSize) / kRfStep + 1; }
+
+int vtc_frames_per_window(const vtc_model* m) { return m ? m->T : VTC_ERR_ARG; }
+
+const char* vtc_profile_class_name(int32_t c) { return (c >= 0 && c < VTC_PROF_CLASSES) ? kProfNames[c] : ""; }
+
+void vtc_destroy(vtc_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : m->allocs) (void)hipFree(p);
+  for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
+                  (void*)m->dec_summary, (void*)m->dec_max})
+    if (p) (void)hipFree(p);
+  if (m->h_stage) (void)hipHostFree(m->h_stage);
+  for (auto& e : m->slot_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete m;
+}
+
+int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model** out) {
+  if (!spec || !w || !out) return fail(nullptr, VTC_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (spec->abi_version != VTC_ABI_VERSION) return fail(nullptr, VTC_ERR_ARG, "ABI version %d != %d", spec->abi_version, VTC_ABI_VERSION);
+  if (spec->n_labels < 1 || spec->n_labels > VTC_MAX_LABELS) return fail(nullptr, VTC_ERR_ARG, "n_labels %d out of range", spec->n_labels);
+  if (spec->max_batch < 1 || spec->max_batch > 4096) return fail(nullptr, VTC_ERR_ARG, "max_batch %d out of range", spec->max_batch);
+  if (spec->mfma_dtype != 0 && spec->mfma_dtype != 1) return fail(nullptr, VTC_ERR_ARG, "mfma_dtype must be 0 (bf16) or 1 (f16)");
+  const long long T = vtc_frames_for_samples(spec->window_samples);
+  if (T < 1 || T > 512)
+    return fail(nullptr, VTC_ERR_ARG, "window of %d samples gives %lld frames; supported 1..512 (K/V of a head must fit LDS)",
+                spec->window_samples, T);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VTC_ERR_NO_GPU, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(nullptr, VTC_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, VTC_ERR_HIP, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, VTC_ERR_NO_GPU, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+  vtc_model* m = new vtc_model();
+  auto bail = [&](int rc) { g_create_error = m->err; vtc_destroy(m); return rc; };
+  m->spec = *spec;
+  m->device = device;
+  m->f16 = spec->mfma_dtype == 1;
+  m->T = (int)T;
+  {
+    int n = spec->window_samples;
+    for (int i = 0; i < 7; ++i) { n = (n - kKernels[i]) / kStrides[i] + 1; m->L[i] = n; }
+  }
+  if (m->L[6] != m->T) return bail(fail(m, VTC_ERR_ARG, "geometry mismatch"));
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipSetDevice(%d) failed", device));
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
+  const bool f16 = m->f16;
+  // ---- weights
+  TRY(upload_f32(m, &m->conv0_w, w->conv_w[0], 512 * 10));
+  TRY(upload_f32(m, &m->gn_w, w->gn_w, 512));
+  TRY(upload_f32(m, &m->gn_b, w->gn_b, 512));
+  for (int i = 1; i < 7; ++i) {
+    if (!w->conv_w[i]) return bail(fail(m, VTC_ERR_ARG, "missing conv weight %d", i));
+    TRY(upload_h16(m, &m->conv_w[i], pack_conv(w->conv_w[i], 512, 512, kKernels[i], f16)));
+  }
+  TRY(upload_f32(m, &m->fp_ln_w, w->fp_ln_w, 512));
+  TRY(upload_f32(m, &m->fp_ln_b, w->fp_ln_b, 512));
+  if (!w->fp_w || !w->pos_w) return bail(fail(m, VTC_ERR_ARG, "missing projection / positional weight"));
+  TRY(upload_h16(m, &m->fp_w, pack_linear(w->fp_w, 768, 512, f16)));
+  TRY(upload_f32(m, &m->fp_b, w->fp_b, 768));
+  TRY(upload_h16(m, &m->pos_w, pack_posconv(w->pos_w, f16)));
+  TRY(upload_f32(m, &m->pos_b, w->pos_b, 768));
+  TRY(upload_f32(m, &m->enc_ln_w, w->enc_ln_w, 768));
+  TRY(upload_f32(m, &m->enc_ln_b, w->enc_ln_b, 768));
+  for (int l = 0; l < VTC_N_LAYERS; ++l) {
+    const vtc_layer_weights& s = w->layer[l];
+    LayerDev& d = m->layer[l];
+    if (!s.q_w || !s.k_w || !s.v_w || !s.q_b || !s.k_b || !s.v_b || !s.o_w || !s.ff1_w || !s.ff2_w)
+      return bail(fail(m, VTC_ERR_ARG, "missing weight in layer %d", l));
+    // fused QKV [2304][768]; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) is folded in (exact: 2^-3)
+    std::vector<unsigned short> qkv = pack_linear(s.q_w, 768, 768, f16, 0.125f, 768);
+    std::vector<unsigned short> kk = pack_linear(s.k_w, 768, 768, f16), vv = pack_linear(s.v_w, 768, 768, f16);
+    qkv.insert(qkv.end(), kk.begin(), kk.end());
+    qkv.insert(qkv.end(), vv.begin(), vv.end());
+    TRY(upload_h16(m, &d.qkv_w, qkv));
+    std::vector<float> qb(2304);
+    for (int i = 0; i < 768; ++i) { qb[i] = s.q_b[i] * 0.125f; qb[768 + i] = s.k_b[i]; qb[1536 + i] = s.v_b[i]; }
+    TRY(upload_f32(m, &d.qkv_b, qb.data(), 2304));
+    TRY(upload_h16(m, &d.o_w, pack_linear(s.o_w, 768, 768, f16)));
+    TRY(upload_f32(m, &d.o_b, s.o_b, 768));
+    TRY(upload_f32(m, &d.ln1_w, s.ln1_w, 768));
+    TRY(upload_f32(m, &d.ln1_b, s.ln1_b, 768));
+    TRY(upload_h16(m, &d.ff1_w, pack_linear(s.ff1_w, 3072, 768, f16)));
+    TRY(upload_f32(m, &d.ff1_b, s.ff1_b, 3072));
+    TRY(upload_h16(m, &d.ff2_w, pack_linear(s.ff2_w, 768, 3072, f16)));
+    TRY(upload_f32(m, &d.ff2_b, s.ff2_b, 768));
+    TRY(upload_f32(m, &d.ln2_w, s.ln2_w, 768));
+    TRY(upload_f32(m, &d.ln2_b, s.ln2_b, 768));
+  }
+  TRY(upload_f32(m, &m->head_w, w->head_w, (size_t)spec->n_labels * 768));
+  TRY(upload_f32(m, &m->head_b, w->head_b, spec->n_labels));
+
+  // ---- workspace
+  const size_t B = spec->max_batch, MT = B * (size_t)m->T;
+  TRY(dev_alloc(m, &m->actA, B * m->L[0] * 512));
+  TRY(dev_alloc(m, &m->actB, std::max(B * (size_t)m->L[1] * 512, MT * 512)));
+  TRY(dev_alloc(m, &m->h0, MT * 768));
+  TRY(dev_alloc(m, &m->tmp32, MT * 768));
+  TRY(dev_alloc(m, &m->x32, MT * 768));
+  TRY(dev_alloc(m, &m->x16, MT * 768));
+  TRY(dev_alloc(m, &m->qkv16, MT * 2304));
+  TRY(dev_alloc(m, &m->ctx16, MT * 768));
+  TRY(dev_alloc(m, &m->ffn16, MT * 3072));
+  TRY(dev_alloc(m, &m->posin, B * 16 * (size_t)(m->T + 128) * 48));
+  TRY(dev_alloc(m, &m->gn_scale, B * 512));
+  TRY(dev_alloc(m, &m->gn_shift, B * 512));
+  m->nchunk = (m->L[0] + kStatChunk - 1) / kStatChunk;
+  TRY(dev_alloc(m, &m->mom_partial, B * m->nchunk * kStatN));
+  TRY(dev_alloc(m, &m->d_start, B));
+  TRY(dev_alloc(m, &m->d_dst, B));
+  TRY(dev_alloc(m, &m->d_valid, B));
+  TRY(dev_alloc(m, &m->d_keep, B));
+  if (hipHostMalloc((void**)&m->h_stage, (size_t)kSlots * B * 24, hipHostMallocDefault) != hipSuccess)
+    return bail(fail(m, VTC_ERR_HIP, "hipHostMalloc(staging) failed"));
+  for (auto& e : m->slot_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipEventCreate failed"));
+
+  // attention needs up to 128 KiB of dynamic LDS
+  const int lds = ((m->T + 31) / 32) * 32 * 128 * 2;
+  hipError_t e = f16 ? hipFuncSetAttribute((const void*)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                     : hipFuncSetAttribute((const void*)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipFuncSetAttribute(attention LDS %d) -> %s", lds, hipGetErrorString(e)));
+#undef TRY
+  *out = m;
+  return VTC_OK;
+}
+
+int vtc_forward_windows(vtc_model* m, const float* wav, const int64_t* start, const int32_t* valid, const int64_t* dst_row,
+                        const int32_t* keep, int32_t nw, float* logits, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!wav || !start || !valid || !dst_row || !keep || !logits) return fail(m, VTC_ERR_ARG, "null argument");
+  if (nw < 1 || nw > m->spec.max_batch) return fail(m, VTC_ERR_ARG, "n_windows %d not in 1..%d", nw, m->spec.max_batch);
+  for (int i = 0; i < nw; ++i) {
+    if (start[i] < 0 || valid[i] < 0 || valid[i] > m->spec.window_samples || keep[i] < 0 || keep[i] > m->T || dst_row[i] < 0)
+      return fail(m, VTC_ERR_ARG, "window %d: start %lld valid %d keep %d dst_row %lld out of range", i, (long long)start[i],
+                  valid[i], keep[i], (long long)dst_row[i]);
+  }
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t B = m->spec.max_batch;
+  const int slot = m->slot;
+  m->slot = (m->slot + 1) % kSlots;
+  if (m->slot_used[slot]) HIP_TRY(m, hipEventSynchronize(m->slot_ev[slot]));
+  char* hs = m->h_stage + (size_t)slot * B * 24;
+  long long* hs_start = (long long*)hs;
+  long long* hs_dst = (long long*)(hs + B * 8);
+  int* hs_valid = (int*)(hs + B * 16);
+  int* hs_keep = (int*)(hs + B * 20);
+  for (int i = 0; i < nw; ++i) { hs_start[i] = start[i]; hs_dst[i] = dst_row[i]; hs_valid[i] = valid[i]; hs_keep[i] = keep[i]; }
+  HIP_TRY(m, hipMemcpyAsync(m->d_start, hs_start, nw * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipMemcpyAsync(m->d_dst, hs_dst, nw * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipMemcpyAsync(m->d_valid, hs_valid, nw * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipMemcpyAsync(m->d_keep, hs_keep, nw * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipEventRecord(m->slot_ev[slot], s));
+  m->slot_used[slot] = true;
+  const int rc = m->f16 ? forward_impl<true>(m, wav, nw, logits, s) : forward_impl<false>(m, wav, nw, logits, s);
+  if (rc) return rc;
+  HIP_TRY(m, hipGetLastError());
+  return VTC_OK;
+}
+
+int vtc_infer_waveform(vtc_model* m, const float* wav, int64_t n_samples, int32_t batch, float* logits, int64_t* n_frames,
+                       void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!wav || !logits || !n_frames) return fail(m, VTC_ERR_ARG, "null argument");
+  if (batch < 1) return fail(m, VTC_ERR_ARG, "batch %d < 1", batch);
+  if (batch > m->spec.max_batch) batch = m->spec.max_batch;
+  *n_frames = 0;
+  if (n_samples < kRfSize) return fail(m, VTC_ERR_SHORT, "audio too short: %lld samples < %d", (long long)n_samples, kRfSize);
+  const long long W = m->spec.window_samples, T = m->T, step = T * kRfStep;  // chunk_artifact.py:71-73
+  std::vector<int64_t> start, dst;
+  std::vector<int32_t> valid, keep;
+  long long total = 0;
+  for (long long s0 = 0; n_samples - s0 >= kRfSize; s0 += step) {
+    const long long rem = n_samples - s0;
+    start.push_back(s0);
+    valid.push_back((int32_t)std::min(rem, W));
+    const long long k = std::min<long long>(T, vtc_frames_for_samples(rem));
+    keep.push_back((int32_t)k);
+    dst.push_back(total);
+    total += k;
+  }
+  for (size_t i = 0; i < start.size(); i += batch) {
+    const int nw = (int)std::min<size_t>(batch, start.size() - i);
+    const int rc = vtc_forward_windows(m, wav, &start[i], &valid[i], &dst[i], &keep[i], nw, logits, stream);
+    if (rc) return rc;
+  }
+  *n_frames = total;
+  return VTC_OK;
+}
+
+int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi, int64_t* out_start,
+               int64_t* out_end, int32_t* out_label, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
+               void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !lo || !hi || !n_out || (cap > 0 && (!out_start || !out_end || !out_label)))
+    return fail(m, VTC_ERR_ARG, "null argument");
+  if (n < 1 || n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  const int nl = m->spec.n_labels;
+  DecodeParams p{};
+  p.logits = logits; p.n = n; p.nl = nl; p.nblk = (int)((n + 255) / 256);
+  for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
+  const long long dcap = m->dec_frames_cap / 2 + 1;
+  LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4 * 2, s, {
+    hipLaunchKernelGGL(decode_count_kernel, dim3(p.nblk), dim3(256), 0, s, p, m->dec_counts, m->dec_sig, m->dec_max);
+    hipLaunchKernelGGL(decode_scan_kernel, dim3(2 * nl), dim3(1024), 0, s, m->dec_counts, p.nblk, m->dec_totals, m->dec_sig,
+                       m->dec_max, m->dec_summary);
+    hipLaunchKernelGGL(decode_emit_kernel, dim3(p.nblk), dim3(256), 0, s, p, m->dec_counts, dcap, m->dec_start, m->dec_end);
+  });
+  int totals[2 * VTC_MAX_LABELS];
+  double summary[2];
+  HIP_TRY(m, hipMemcpyAsync(totals, m->dec_totals, sizeof(int) * 2 * nl, hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipMemcpyAsync(summary, m->dec_summary, sizeof summary, hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  if (max_logit) *max_logit = (float)summary[1];
+  if (mean_sigmoid) *mean_sigmoid = summary[0] / ((double)n * nl);
+  long long total = 0;
+  for (int l = 0; l < nl; ++l) {
+    if (totals[l] != totals[nl + l]) return fail(m, VTC_ERR_HIP, "decode: label %d has %d starts but %d ends", l, totals[l], totals[nl + l]);
+    total += totals[l];
+  }
+  *n_out = total;
+  if (total > cap) return fail(m, VTC_ERR_CAPACITY, "decode: %lld intervals, caller capacity %lld", total, (long long)cap);
+  std::vector<int> hs, he;
+  long long at = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int c = totals[l];
+    if (!c) continue;
+    hs.resize(c); he.resize(c);
+    HIP_TRY(m, hipMemcpy(hs.data(), m->dec_start + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
+    HIP_TRY(m, hipMemcpy(he.data(), m->dec_end + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < c; ++k, ++at) {
+      out_start[at] = (int64_t)hs[k] * kRfStep;
+      out_end[at] = (int64_t)he[k] * kRfStep + kRfSize;
+      out_label[at] = l;
+    }
+  }
+  return VTC_OK;
+}
+
+int vtc_debug_stop_after(vtc_model* m, int32_t stage) {
+  if (!m || stage < -1 || stage > 9 + VTC_N_LAYERS - 1) return VTC_ERR_ARG;
+  m->debug_stop = stage;
+  return VTC_OK;
+}
+
+int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t nw, float* out, int64_t cap) {
+  if (!m || !out || nw < 1 || nw > m->spec.max_batch) return VTC_ERR_ARG;
+  if (hipSetDevice(m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(m, VTC_ERR_HIP, "sync failed");
+  const void* src = nullptr;
+  long long n = 0;
+  bool is16 = true;
+  if (stage >= 0 && stage <= 6) { src = (stage % 2 == 0) ? m->actA : m->actB; n = (long long)nw * m->L[stage] * 512; }
+  else if (stage == 7) { src = m->h0; n = (long long)nw * m->T * 768; is16 = false; }
+  else if (stage >= 8 && stage < 9 + VTC_N_LAYERS) { src = m->x32; n = (long long)nw * m->T * 768; is16 = false; }
+  else return fail(m, VTC_ERR_ARG, "unknown stage %d", stage);
+  if (n > cap) return fail(m, VTC_ERR_CAPACITY, "stage %d needs %lld floats", stage, n);
+  if (!is16) {
+    if (hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(m, VTC_ERR_HIP, "copy failed");
+    return n;
+  }
+  std::vector<unsigned short> tmp(n);
+  if (hipMemcpy(tmp.data(), src, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(m, VTC_ERR_HIP, "copy failed");
+  for (long long i = 0; i < n; ++i) {
+    if (m->f16) { _Float16 h; memcpy(&h, &tmp[i], 2); out[i] = (float)h; }
+    else { unsigned u = (unsigned)tmp[i] << 16; memcpy(&out[i], &u, 4); }
+  }
+  return n;
+}
+
+int vtc_profile_enable(vtc_model* m, int32_t on) {
+  if (!m) return VTC_ERR_ARG;
+  m->prof_on = on != 0;
+  m->prof.clear();
+  m->ev_next = 0;
+  return VTC_OK;
+}
+
+int vtc_profile_read(vtc_model* m, double* ms, int64_t* launches, double* flops, double* bytes) {
+  if (!m || !ms || !launches || !flops || !bytes) return VTC_ERR_ARG;
+  HIP_TRY(m, hipSetDevice(m->device));
+  HIP_TRY(m, hipDeviceSynchronize());
+  for (int c = 0; c < VTC_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; bytes[c] = 0; }
+  for (const ProfRec& r : m->prof) {
+    float t = 0.f;
+    HIP_TRY(m, hipEventElapsedTime(&t, r.e0, r.e1));
+    ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes;
+  }
+  m->prof.clear();
+  m->ev_next = 0;
+  return VTC_OK;
+}
+
+}  // extern "C"

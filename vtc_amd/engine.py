@@ -1,0 +1,200 @@
+"""VtcEngine -- the Python owner of one `vtc_model` handle (one per GPU / process).
+
+PyTorch is plumbing here: device buffers, streams and the tensors handed back to the host code.
+All arithmetic of the hot path runs in libvtc_amd.so (hand-written gfx950 kernels).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+SAMPLE_RATE = 16_000
+RF_STEP = 320   # reference: src/analysis/chunk_artifact.py:51
+RF_SIZE = 400   # reference: src/analysis/chunk_artifact.py:11-13
+DTYPES = {"bf16": 0, "f16": 1}
+
+
+def frames_for_samples(n_samples: int) -> int:
+    return 0 if n_samples < RF_SIZE else (n_samples - RF_SIZE) // RF_STEP + 1
+
+
+def _np32(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        t = t.detach().to("cpu", torch.float32).numpy()
+    return np.ascontiguousarray(np.asarray(t, dtype=np.float32))
+
+
+def fold_weight_norm(sd: dict) -> np.ndarray:
+    """Positional conv weight with weight_norm(dim=2) folded: W = g * v / ||v|| over dims (0,1)
+    (HF modeling_hubert.py:60-78).  Accepts the parametrised, the legacy (_g/_v) or a plain weight."""
+    p = "encoder.pos_conv_embed.conv."
+    if p + "parametrizations.weight.original1" in sd:
+        g, v = _np32(sd[p + "parametrizations.weight.original0"]), _np32(sd[p + "parametrizations.weight.original1"])
+    elif p + "weight_v" in sd:
+        g, v = _np32(sd[p + "weight_g"]), _np32(sd[p + "weight_v"])
+    else:
+        return _np32(sd[p + "weight"])
+    norm = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+    return np.ascontiguousarray(g * v / norm)
+
+
+class VtcEngine:
+    def __init__(self, state_dict: dict, n_labels: int, chunk_duration_s: float, max_batch: int = 64,
+                 mfma_dtype: str = "f16", device: int | str | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("vtc_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        if mfma_dtype not in DTYPES:
+            raise ValueError(f"mfma_dtype must be one of {list(DTYPES)}")
+        self._lib = L.load()
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"vtc_amd runs on ROCm GPUs only, got device {self.device}")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device(f"cuda:{dev_index}")
+        self.n_labels = int(n_labels)
+        self.window_samples = int(round(chunk_duration_s * SAMPLE_RATE))
+        self.max_batch = int(max_batch)
+        self.mfma_dtype = mfma_dtype
+        self._handle = C.c_void_p()
+
+        keep = []  # numpy arrays must outlive vtc_create
+
+        def ptr(name_or_arr):
+            a = _np32(state_dict[name_or_arr]) if isinstance(name_or_arr, str) else _np32(name_or_arr)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_float))
+
+        w = L.VtcWeights()
+        for i in range(7):
+            w.conv_w[i] = ptr(f"feature_extractor.conv_layers.{i}.conv.weight")
+        w.gn_w, w.gn_b = ptr("feature_extractor.conv_layers.0.layer_norm.weight"), ptr("feature_extractor.conv_layers.0.layer_norm.bias")
+        w.fp_ln_w, w.fp_ln_b = ptr("feature_projection.layer_norm.weight"), ptr("feature_projection.layer_norm.bias")
+        w.fp_w, w.fp_b = ptr("feature_projection.projection.weight"), ptr("feature_projection.projection.bias")
+        w.pos_w, w.pos_b = ptr(fold_weight_norm(state_dict)), ptr("encoder.pos_conv_embed.conv.bias")
+        w.enc_ln_w, w.enc_ln_b = ptr("encoder.layer_norm.weight"), ptr("encoder.layer_norm.bias")
+        for l in range(L.N_LAYERS):
+            p = f"encoder.layers.{l}."
+            lw = w.layer[l]
+            for short, long in (("q", "attention.q_proj"), ("k", "attention.k_proj"), ("v", "attention.v_proj"),
+                                ("o", "attention.out_proj"), ("ff1", "feed_forward.intermediate_dense"),
+                                ("ff2", "feed_forward.output_dense"), ("ln1", "layer_norm"), ("ln2", "final_layer_norm")):
+                setattr(lw, short + "_w", ptr(p + long + ".weight"))
+                setattr(lw, short + "_b", ptr(p + long + ".bias"))
+        hw = _np32(state_dict["head.weight"])
+        if hw.shape != (self.n_labels, 768):
+            raise ValueError(f"head.weight has shape {hw.shape}, expected ({self.n_labels}, 768)")
+        w.head_w, w.head_b = ptr(hw), ptr("head.bias")
+
+        spec = L.VtcSpec(abi_version=L.ABI_VERSION, n_labels=self.n_labels, window_samples=self.window_samples,
+                         max_batch=self.max_batch, mfma_dtype=DTYPES[mfma_dtype])
+        L.check(self._lib.vtc_create(C.byref(spec), C.byref(w), dev_index, C.byref(self._handle)), None)
+        self.frames_per_window = int(self._lib.vtc_frames_per_window(self._handle))
+        self.step = self.frames_per_window * RF_STEP   # reference: chunk_artifact.py:71-73
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_handle", None) and self._handle.value:
+            self._lib.vtc_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_wav(self, wav: torch.Tensor):
+        if wav.device != self.device or wav.dtype != torch.float32 or not wav.is_contiguous() or wav.dim() != 1:
+            raise ValueError("waveform must be a contiguous 1-D float32 tensor on the engine's device")
+
+    # ------------------------------------------------------------------ forward
+    def forward_windows(self, wav: torch.Tensor, start, valid, dst_row, keep, logits: torch.Tensor) -> None:
+        """Run one batch of windows (include/vtc_amd.h: vtc_forward_windows)."""
+        self._check_wav(wav)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        valid = np.ascontiguousarray(valid, dtype=np.int32)
+        dst_row = np.ascontiguousarray(dst_row, dtype=np.int64)
+        keep = np.ascontiguousarray(keep, dtype=np.int32)
+        n = len(start)
+        if not (len(valid) == len(dst_row) == len(keep) == n):
+            raise ValueError("window arrays differ in length")
+        if n and int((start + valid).max()) > wav.numel():
+            raise ValueError("window reaches past the end of the waveform arena")
+        if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
+        if n and int((dst_row + keep).max()) * self.n_labels > logits.numel():
+            raise ValueError("logits buffer too small for dst_row + keep")
+        L.check(self._lib.vtc_forward_windows(
+            self._handle, C.c_void_p(wav.data_ptr()), start.ctypes.data_as(L._i64p), valid.ctypes.data_as(L._i32p),
+            dst_row.ctypes.data_as(L._i64p), keep.ctypes.data_as(L._i32p), n, C.c_void_p(logits.data_ptr()),
+            self._stream()), self._handle)
+
+    def infer_waveform(self, wav: torch.Tensor, batch_size: int | None = None) -> torch.Tensor:
+        """Stitched logits (n_frames, n_labels) of one waveform (include/vtc_amd.h: vtc_infer_waveform)."""
+        self._check_wav(wav)
+        n = int(wav.numel())
+        rows = frames_for_samples(n)
+        logits = torch.empty((max(rows, 1), self.n_labels), dtype=torch.float32, device=self.device)
+        nf = C.c_int64(0)
+        L.check(self._lib.vtc_infer_waveform(self._handle, C.c_void_p(wav.data_ptr()), n,
+                                             int(batch_size or self.max_batch), C.c_void_p(logits.data_ptr()),
+                                             C.byref(nf), self._stream()), self._handle)
+        return logits[: nf.value]
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, logits: torch.Tensor, lo_logit, hi_logit):
+        """Threshold + run-length decode on the GPU (include/vtc_amd.h: vtc_decode).
+
+        Returns (start_samples[int64], end_samples[int64], label_index[int32], max_logit, mean_sigmoid)."""
+        if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
+        n = int(logits.shape[0])
+        lo = np.ascontiguousarray(lo_logit, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_logit, dtype=np.float32)
+        if len(lo) != self.n_labels or len(hi) != self.n_labels:
+            raise ValueError("need one lower and one upper bound per label")
+        cap = max(1024, (n // 2 + 1) * self.n_labels)
+        s = np.empty(cap, dtype=np.int64)
+        e = np.empty(cap, dtype=np.int64)
+        lab = np.empty(cap, dtype=np.int32)
+        n_out, mx, mean = C.c_int64(0), C.c_float(0), C.c_double(0)
+        L.check(self._lib.vtc_decode(self._handle, C.c_void_p(logits.data_ptr()), n, lo.ctypes.data_as(L._f32p),
+                                     hi.ctypes.data_as(L._f32p), s.ctypes.data_as(L._i64p), e.ctypes.data_as(L._i64p),
+                                     lab.ctypes.data_as(L._i32p), cap, C.byref(n_out), C.byref(mx), C.byref(mean),
+                                     self._stream()), self._handle)
+        k = n_out.value
+        return s[:k].copy(), e[:k].copy(), lab[:k].copy(), float(mx.value), float(mean.value)
+
+    # ------------------------------------------------------------------ test / bench hooks
+    def debug_stop_after(self, stage: int) -> None:
+        L.check(self._lib.vtc_debug_stop_after(self._handle, stage), self._handle)
+
+    def debug_stage(self, stage: int, n_windows: int, n_elems: int) -> np.ndarray:
+        out = np.empty(n_elems, dtype=np.float32)
+        got = self._lib.vtc_debug_stage(self._handle, stage, n_windows, out.ctypes.data_as(L._f32p), n_elems)
+        if got < 0:
+            L.check(int(got), self._handle)
+        return out[:got]
+
+    def profile_enable(self, on: bool = True) -> None:
+        L.check(self._lib.vtc_profile_enable(self._handle, 1 if on else 0), self._handle)
+
+    def profile_read(self) -> dict:
+        ms = (C.c_double * L.PROF_CLASSES)()
+        cnt = (C.c_int64 * L.PROF_CLASSES)()
+        fl = (C.c_double * L.PROF_CLASSES)()
+        by = (C.c_double * L.PROF_CLASSES)()
+        L.check(self._lib.vtc_profile_read(self._handle, ms, cnt, fl, by), self._handle)
+        out = {}
+        for c in range(L.PROF_CLASSES):
+            name = self._lib.vtc_profile_class_name(c).decode()
+            out[name] = dict(ms=ms[c], launches=int(cnt[c]), flops=fl[c], bytes=by[c])
+        return out
