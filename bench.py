@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""VTC hot-path benchmark (BASELINE.json metric: audio-hours/sec).
+
+A *step* is one pass of the hot path over one batch: `--batch` windows of `--chunk` seconds of
+synthetic 16 kHz audio (already resident in HBM) -> BabyHuBERT forward -> stitched logits ->
+threshold/run-length decode to (start, end, label) triples on the host.  Workload at N=1 is
+BASELINE.json configs[1]: fixed 10 s windows, batch 64, 16-bit MFMA transformer.
+
+N > 1: one process per GPU (torch.distributed launch), files/windows are sharded, no collective in the
+data path; the only communication is the timing barrier + max-over-ranks.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from vtc_amd import synth  # noqa: E402
+from vtc_amd.engine import VtcEngine  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense 16-bit MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_gflop_per_window(T: int, L: list[int]) -> float:
+    """BASELINE.md section 2 formulae (head excluded)."""
+    kern = (10, 3, 3, 3, 3, 2, 2)
+    conv = L[0] * 512 * 1 * 10 + sum(L[i] * 512 * 512 * kern[i] for i in range(1, 7))
+    proj = T * 512 * 768
+    pos = T * 768 * 48 * 128
+    lin = 12 * T * (4 * 768 * 768 + 2 * 768 * 3072)
+    att = 12 * 2 * T * T * 768
+    return 2.0 * (conv + proj + pos + lin + att) / 1e9
+
+
+def conv_lengths(w: int) -> list[int]:
+    out = []
+    for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        w = (w - k) // s + 1
+        out.append(w)
+    return out
+
+
+def cpu_baseline(chunk_s: float, n_windows: int, batch: int) -> dict:
+    """The fp32 CPU oracle (oracle/vtc_oracle.py) timed on this host's cores on a bounded sample."""
+    from oracle import vtc_oracle as O
+    threads = torch.get_num_threads()
+    w = O.make_weights(seed=0)
+    W = int(round(chunk_s * 16000))
+    T = O.conv_out_len(W)
+    audio = synth.synth_audio((n_windows * T * 320 + W) / 16000.0, seed=1000)
+    t0 = time.perf_counter()
+    logits = O.apply_model_on_waveform(w, audio, chunk_s, batch_size=batch)
+    mask = O.apply_thresholds(logits, {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in O.DEFAULT_LABELS})
+    O.create_intervals(mask)
+    dt = time.perf_counter() - t0
+    hours = logits.shape[0] * 320 / 16000.0 / 3600.0
+    return {"value": hours / dt, "unit": "audio-hours/sec", "cores": threads, "kind": "port",
+            "sample": f"{logits.shape[0] // T} windows x {chunk_s:g} s, batch {batch}, fp32 PyTorch-CPU oracle, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--chunk", type=float, default=10.0)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=24)
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    weights = synth.make_weights(seed=0)
+    eng = VtcEngine(weights, n_labels=4, chunk_duration_s=args.chunk, max_batch=args.batch, mfma_dtype=args.dtype,
+                    device=dev)
+    T, W, step = eng.frames_per_window, eng.window_samples, eng.step
+    L = conv_lengths(W)
+
+    # one arena of contiguous synthetic audio per rank (file-level sharding: each rank has its own files)
+    n_arena = 2
+    arena_len = (args.batch - 1) * step + W
+    arenas = [torch.from_numpy(synth.synth_audio(arena_len / 16000.0, seed=1000 + rank * 16 + i)[:arena_len]).to(dev)
+              for i in range(n_arena)]
+    start = np.arange(args.batch, dtype=np.int64) * step
+    valid = np.full(args.batch, W, dtype=np.int32)
+    dst = np.arange(args.batch, dtype=np.int64) * T
+    keep = np.full(args.batch, T, dtype=np.int32)
+    logits = torch.empty((args.batch * T, 4), dtype=torch.float32, device=dev)
+    lo = np.zeros(4, dtype=np.float32)            # sigmoid threshold 0.5 <=> logit 0
+    hi = np.full(4, np.inf, dtype=np.float32)
+
+    def one_step(i: int) -> int:
+        eng.forward_windows(arenas[i % n_arena], start, valid, dst, keep, logits)
+        s, e, lab, _, _ = eng.decode(logits, lo, hi)
+        return len(s)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    t0 = time.perf_counter()
+    nseg = 0
+    for i in range(args.steps):
+        nseg += one_step(i)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read() if not args.no_profile else None
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    if rank == 0:
+        hours_per_step = args.batch * step / 16000.0 / 3600.0
+        value = world * args.steps * hours_per_step / elapsed
+        gflop_win = algorithmic_gflop_per_window(T, L)
+        out = {
+            "metric": "VTC audio-hours/sec (node)", "value": value, "unit": "audio-hours/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (seeded harmonic bursts + noise; seeded random BabyHuBERT-base weights)",
+            "config": {"workload": f"BASELINE configs[1]: fixed {args.chunk:g} s windows ({W} samples -> {T} frames), "
+                                   f"batch {args.batch}, forward + threshold/run-length decode, inputs resident in HBM",
+                       "batch_windows": args.batch, "chunk_duration_s": args.chunk, "frames_per_window": T,
+                       "parallelism": f"file-sharded x{world}, no collective"},
+            "algorithmic_gflop_per_window": gflop_win,
+            "end_to_end_tflops": world * args.steps * args.batch * gflop_win / 1e3 / elapsed,
+            "segments_per_step": nseg / max(args.steps, 1),
+        }
+        if prof is not None:
+            g = prof["gemm_mfma"]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (all dense contractions: conv1-6 implicit GEMM, "
+                               "projection, pos-conv, QKV, out-proj, FFN)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches_per_step": g["launches"] / args.steps,
+                               "avg_launch_ms": g["ms"] / max(g["launches"], 1)}
+            c = prof["conv0_apply"]
+            if c["ms"] > 0:
+                gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9
+                out["roofline_hbm"] = {"bound": "hbm", "kernel": "conv0_apply_kernel (conv0 + GroupNorm + GELU)",
+                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                       "traffic": None, "avg_launch_ms": c["ms"] / max(c["launches"], 1)}
+            out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.chunk, args.cpu_windows, 8)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

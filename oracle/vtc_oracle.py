@@ -140,7 +140,7 @@ def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0) -> di
     v = randn(768, 48, 128, std=(48 * 128) ** -0.5)
     w["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
     w["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (
-        v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt() * (1.0 + randn(1, 1, 128, std=0.1))
+        v.double().pow(2).sum(dim=(0, 1), keepdim=True).sqrt().float() * (1.0 + randn(1, 1, 128, std=0.1))
     )
     w["encoder.pos_conv_embed.conv.bias"] = randn(768, std=0.02)
     w["encoder.layer_norm.weight"] = 1.0 + randn(768, std=0.1)

@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI, libvtc_amd.so) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full size (10 s windows,
+batch 64) -- through size-independent properties.
+
+Tolerances are BASELINE.json north_star's: per-frame logits within 2e-2 abs, frame-label agreement >= 99.9 %,
+integer/index work (tiling, stitching, threshold decode) bit-exact.
+"""
+
+import json
+import math
+
+import numpy as np
+import pyarrow.parquet as pq
+import pytest
+import torch
+
+from oracle import vtc_oracle as O
+from vtc_amd import lib, synth
+from vtc_amd.segma_compat.inference import logit_bounds
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-2          # north_star: per-frame logits within 2e-2 abs
+AGREEMENT = 0.999         # north_star: per-frame label agreement >= 99.9 %
+THR = {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in O.DEFAULT_LABELS}
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return O.make_weights(seed=0)
+
+
+def _engine(weights, chunk, batch, dtype="f16"):
+    from vtc_amd.engine import VtcEngine
+    return VtcEngine(weights, n_labels=4, chunk_duration_s=chunk, max_batch=batch, mfma_dtype=dtype, device=0)
+
+
+def _conv_lengths(w):
+    out = []
+    for k, s in zip(O.CONV_KERNELS, O.CONV_STRIDES):
+        w = (w - k) // s + 1
+        out.append(w)
+    return out
+
+
+# ----------------------------------------------------------------------------- encoder stages
+@pytest.mark.parametrize("dtype,conv_tol,hid_tol", [("f16", 1e-2, 1.5e-2), ("bf16", 6e-2, 1.2e-1)])
+def test_every_stage_against_oracle(weights, dtype, conv_tol, hid_tol):
+    chunk, B = 1.0, 3
+    W = 16000
+    T = O.conv_out_len(W)
+    rng = np.random.default_rng(1)
+    wav = rng.standard_normal((B, W), dtype=np.float32) * np.float32(0.1)
+    wav[-1, W // 2:] = 0
+    with torch.no_grad():
+        st = O.encoder_stages(weights, torch.from_numpy(wav))
+    eng = _engine(weights, chunk, B, dtype)
+    arena = torch.from_numpy(wav.reshape(-1).copy()).cuda()
+    start, valid = np.arange(B) * W, np.full(B, W)
+    valid[-1] = W // 2          # the tail of the last window is zero padding supplied by the kernel
+    dst, keep = np.arange(B) * T, np.full(B, T)
+    logits = torch.zeros((B * T, 4), device="cuda")
+    names = [f"conv{i}" for i in range(7)] + ["proj", "enc_in"] + [f"layer{l}" for l in range(12)]
+    for stage, name in enumerate(names):
+        eng.debug_stop_after(stage)
+        eng.forward_windows(arena, start, valid, dst, keep, logits)
+        ref = st[name].transpose(1, 2).contiguous() if stage <= 6 else st[name]
+        got = torch.from_numpy(eng.debug_stage(stage, B, ref.numel()).reshape(ref.shape))
+        err = (got - ref).abs().max().item()
+        assert err <= (conv_tol if stage <= 6 else hid_tol), f"{name}: max abs err {err}"
+    eng.debug_stop_after(-1)
+    eng.forward_windows(arena, start, valid, dst, keep, logits)
+    torch.cuda.synchronize()
+    err = (logits.cpu() - st["logits"].reshape(B * T, 4)).abs().max().item()
+    assert err <= (LOGIT_TOL if dtype == "f16" else 1.2e-1), err
+    eng.close()
+
+
+def test_golden_logits_fixture(weights, golden_dir):
+    """Committed fixture (tests/golden/encoder_1s.npz), no oracle code involved in the expected values."""
+    info = json.loads((golden_dir / "golden_encoder.json").read_text())
+    z = np.load(golden_dir / "encoder_1s.npz")
+    rng = np.random.default_rng(info["seed_input"])
+    wav = rng.standard_normal((2, 16000), dtype=np.float32) * np.float32(0.1)
+    wav[1, 9000:] = 0.0
+    eng = _engine(O.make_weights(seed=info["seed_weights"]), 1.0, 2)
+    T = eng.frames_per_window
+    logits = torch.zeros((2 * T, 4), device="cuda")
+    eng.forward_windows(torch.from_numpy(wav.reshape(-1).copy()).cuda(), [0, 16000], [16000, 16000], [0, T], [T, T], logits)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy().reshape(2, T, 4), z["logits"], atol=LOGIT_TOL, rtol=0)
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- whole files
+def _masks_and_segments(logits_cpu, uid="f"):
+    mask = O.apply_thresholds(logits_cpu, THR)
+    return mask, O.intervals_to_segments(O.create_intervals(mask), uid)
+
+
+@pytest.mark.parametrize("chunk,seconds", [(4.0, 30.7), (10.0, 47.3)])
+def test_file_logits_labels_and_segments(weights, chunk, seconds):
+    """Multi-window file with a ragged tail: tiling, stitching, logits, labels, segments."""
+    wav = synth.synth_audio(seconds, seed=11)
+    ref = O.apply_model_on_waveform(weights, wav, chunk, batch_size=4)
+    eng = _engine(weights, chunk, 3)        # batch 3 -> several forward calls + a short last batch
+    got = eng.infer_waveform(torch.from_numpy(wav).cuda(), batch_size=3)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (O.n_frames_for_samples(len(wav)), 4)
+    diff = (got.cpu() - ref).abs()
+    assert diff.max().item() <= LOGIT_TOL, diff.max().item()
+    m_ref, seg_ref = _masks_and_segments(ref)
+    m_got, seg_got = _masks_and_segments(got.cpu())
+    agree = (m_ref == m_got).float().mean().item()
+    assert agree >= AGREEMENT, agree
+    confident = ref.abs() > LOGIT_TOL
+    assert torch.equal(m_ref[confident], m_got[confident])
+    if torch.equal(m_ref, m_got):
+        assert seg_ref == seg_got
+    # GPU decode of the GPU logits == oracle decode of the same logits (index work: bit exact)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    s, e, lab, max_logit, mean_sig = eng.decode(got.contiguous(), lo, hi)
+    have = [(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s, e, lab)]
+    assert have == O.create_intervals(m_got)
+    mx, mean = O.sigmoid_summary(got.cpu())
+    assert round(float(torch.sigmoid(torch.tensor(max_logit)).item()), 4) == mx
+    assert abs(round(mean_sig, 4) - mean) <= 1e-4
+    eng.close()
+
+
+def test_short_and_edge_lengths(weights):
+    eng = _engine(weights, 1.0, 4)
+    with pytest.raises(lib.VtcError) as ei:
+        eng.infer_waveform(torch.zeros(399, device="cuda"))
+    assert ei.value.status == lib.ERR_SHORT and "too short" in str(ei.value)
+    T = eng.frames_per_window
+    for n in (400, 719, 720, 16000, 16001, T * 320 + 399, T * 320 + 400, 3 * T * 320 + 777):
+        wav = (np.random.default_rng(n).standard_normal(n) * 0.1).astype(np.float32)
+        got = eng.infer_waveform(torch.from_numpy(wav).cuda())
+        ref = O.apply_model_on_waveform(weights, wav, 1.0, batch_size=4)
+        assert got.shape == ref.shape, n
+        assert (got.cpu() - ref).abs().max().item() <= LOGIT_TOL, n
+    with pytest.raises(ValueError):
+        eng.infer_waveform(torch.zeros(1000, device="cuda", dtype=torch.float64))
+    with pytest.raises(lib.VtcError):
+        eng.forward_windows(torch.zeros(16000, device="cuda"), [0] * 5, [16000] * 5, [0] * 5, [T] * 5,
+                            torch.zeros((5 * T, 4), device="cuda"))   # more windows than max_batch
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_batch64_10s_properties(weights):
+    """BASELINE configs[1] shape: 64 windows x 10 s.  Determinism, batch-position invariance (bit exact),
+    stitching layout, and two windows checked against the oracle."""
+    chunk, B = 10.0, 64
+    eng = _engine(weights, chunk, B)
+    T, W, step = eng.frames_per_window, eng.window_samples, eng.step
+    assert (T, W, step) == (499, 160000, 159680)
+    n = (B - 1) * step + W - 12345                      # ragged tail in the last window
+    wav = synth.synth_audio(n / 16000.0, seed=21)[:n]
+    gpu = torch.from_numpy(wav).cuda()
+    a = eng.infer_waveform(gpu)
+    b = eng.infer_waveform(gpu)
+    torch.cuda.synchronize()
+    assert a.shape[0] == O.n_frames_for_samples(n)
+    assert torch.equal(a, b), "two runs differ: the path must be deterministic (reference tests/test_reproducibility.py:212)"
+    assert torch.isfinite(a).all()
+    # the same window alone (batch of 1, other position) gives the same bits
+    for wi in (0, 17, 62):
+        solo = torch.zeros((T, 4), device="cuda")
+        eng.forward_windows(gpu, [wi * step], [W], [0], [T], solo)
+        torch.cuda.synchronize()
+        assert torch.equal(solo, a[wi * T:(wi + 1) * T]), f"window {wi} depends on its batch position"
+    # oracle on two windows (first, and the zero-padded tail)
+    plan = O.plan_windows(n, chunk)
+    for wi in (0, B - 1):
+        x = np.zeros(W, np.float32)
+        x[: plan.valid[wi]] = wav[plan.starts[wi]: plan.starts[wi] + plan.valid[wi]]
+        ref = O.encoder_logits(weights, torch.from_numpy(x[None]))[0][: plan.keep[wi]]
+        got = a[wi * T: wi * T + plan.keep[wi]].cpu()
+        assert (got - ref).abs().max().item() <= LOGIT_TOL
+        assert ((got > 0) == (ref > 0)).float().mean().item() >= AGREEMENT
+    eng.close()
+
+
+def test_bf16_mode_error_is_measured_and_bounded(weights):
+    """bf16 MFMA operands cannot meet the 2e-2 bar on this model (DESIGN.md 'Precision'); the mode stays
+    selectable and its error is pinned here so a regression shows."""
+    wav = synth.synth_audio(12.0, seed=5)
+    ref = O.apply_model_on_waveform(weights, wav, 4.0, batch_size=4)
+    eng = _engine(weights, 4.0, 4, "bf16")
+    got = eng.infer_waveform(torch.from_numpy(wav).cuda()).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 1.5e-1, err
+    assert ((got > 0) == (ref > 0)).float().mean().item() >= 0.98
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- decode
+def _decode_case(eng, logits_np, thr):
+    lo, hi = logit_bounds(thr, O.DEFAULT_LABELS)
+    t = torch.from_numpy(logits_np).cuda()
+    s, e, lab, max_logit, mean_sig = eng.decode(t, lo, hi)
+    have = [(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s, e, lab)]
+    want = O.create_intervals(O.apply_thresholds(torch.from_numpy(logits_np), thr))
+    assert have == want
+    mx, mean = O.sigmoid_summary(torch.from_numpy(logits_np))
+    assert round(float(torch.sigmoid(torch.tensor(max_logit)).item()), 4) == mx
+    assert abs(round(mean_sig, 4) - mean) <= 1e-4
+    return have
+
+
+def test_decode_bit_exact_against_oracle(weights):
+    eng = _engine(weights, 1.0, 1)
+    rng = np.random.default_rng(3)
+    grid = lambda a: (np.round(a * 1024) / 1024).astype(np.float32)   # keeps logits off the 1-ulp sigmoid boundary
+    mixed = dict(THR)
+    mixed["MAL"] = {"lower_bound": 0.3, "upper_bound": 0.9}
+    mixed["OCH"] = {"lower_bound": 0.0, "upper_bound": 1.0}
+    cases = [
+        grid(rng.standard_normal((1, 4))), grid(rng.standard_normal((255, 4))), grid(rng.standard_normal((256, 4))),
+        grid(rng.standard_normal((257, 4))), grid(rng.standard_normal((100_003, 4)) * 2),
+        np.full((1000, 4), 3.0, np.float32), np.full((1000, 4), -3.0, np.float32),
+        np.tile(np.array([[1.0, -1.0, 1.0, -1.0], [-1.0, 1.0, 1.0, -1.0]], np.float32), (700, 1)),
+        np.zeros((513, 4), np.float32),                        # sigmoid(0) == 0.5 -> active (inclusive bound)
+    ]
+    smooth = np.cumsum(rng.standard_normal((300_000, 4)), axis=0) * 0.05   # long runs crossing many blocks
+    cases.append(grid(smooth - smooth.mean(0)))
+    for c in cases:
+        for thr in (THR, mixed):
+            _decode_case(eng, np.ascontiguousarray(c), thr)
+    runs = _decode_case(eng, np.full((1000, 4), 3.0, np.float32), THR)
+    assert runs == [(0, 999 * 320 + 400, l) for l in O.DEFAULT_LABELS]
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- drop-in surface + CLI
+def test_reference_host_flow_through_segma_surface(weights, tmp_path):
+    """The reference's own call sequence (src/pipeline/vtc.py:183-195, 236-243, 84-96, 284-288)."""
+    from vtc_amd.audio import write_wav
+    from vtc_amd.core.intervals import intervals_to_segments
+    from vtc_amd.core.metadata import vtc_meta_row
+    from vtc_amd.segma_compat import install_as_segma
+    install_as_segma()
+    from segma.config import load_config
+    from segma.inference import apply_model_on_audio, apply_thresholds, create_intervals
+    from segma.models import Models
+    from segma.utils.encoders import MultiLabelEncoder
+
+    (tmp_path / "config.yml").write_text("model:\n  name: surgical_hydra\ndata:\n  classes: [FEM, MAL, KCHI, OCH]\n"
+                                         "audio:\n  chunk_duration_s: 4.0\n")
+    wav = synth.synth_audio(9.3, seed=2)
+    write_wav(tmp_path / "a.wav", wav)
+    cfg = load_config(tmp_path / "config.yml")
+    enc = MultiLabelEncoder(labels=cfg.data.classes)
+    model = Models[cfg.model.name].load_from_checkpoint(checkpoint_path="synthetic:0", label_encoder=enc, config=cfg, train=False)
+    model.eval()
+    model.to(torch.device("cuda"))
+    with torch.no_grad():
+        logits_t = apply_model_on_audio(audio_path=tmp_path / "a.wav", model=model, conv_settings=model.conv_settings,
+                                        device="cuda", batch_size=128, chunk_duration_s=cfg.audio.chunk_duration_s)
+    again = apply_model_on_audio(audio_path=tmp_path / "a.wav", model=model, conv_settings=model.conv_settings,
+                                 device="cuda", batch_size=128, chunk_duration_s=cfg.audio.chunk_duration_s)
+    assert torch.equal(logits_t, again)
+    cpu = logits_t.cpu()
+    thresholded = apply_thresholds(cpu, {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in enc.labels}, "cpu").detach()
+    intervals = create_intervals(thresholded, model.conv_settings, enc)
+    assert intervals == O.create_intervals(O.apply_thresholds(cpu, THR))
+    from vtc_amd.audio import read_audio
+    ref = O.apply_model_on_waveform(weights, read_audio(tmp_path / "a.wav"), 4.0)
+    assert (cpu - ref).abs().max().item() <= LOGIT_TOL
+    segs = intervals_to_segments(intervals, "a")
+    row = vtc_meta_row("a", 0.5, segs, *O.sigmoid_summary(cpu))
+    assert row["vtc_n_segments"] == len(segs)
+
+
+def test_cli_outputs_resume_and_error_rows(weights, tmp_path, monkeypatch):
+    from vtc_amd.audio import read_audio, write_wav
+    from vtc_amd.pipeline import vtc as cli
+    from vtc_amd import utils
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    durs = {"f0": 3.2, "f1": 7.9, "f2": 0.02, "f3": 12.0, "f4": 1.0}     # f2 is shorter than the receptive field
+    for i, (uid, d) in enumerate(durs.items()):
+        write_wav(tmp_path / "audio" / f"{uid}.wav", synth.synth_audio(d, seed=40 + i))
+    (tmp_path / "manifests" / "ds.csv").write_text("path\n" + "\n".join(str(tmp_path / "audio" / f"{u}.wav") for u in durs) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    common = dict(config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=4)
+    cli.main("ds", array_id=0, array_count=2, save_logits=True, **common)
+    cli.main("ds", array_id=1, array_count=2, **common)
+    out = tmp_path / "output" / "ds"
+    meta = {r["uid"]: r for f in sorted((out / "vtc_meta").glob("shard_*.parquet")) for r in pq.read_table(f).to_pylist()}
+    assert set(meta) == set(durs)
+    assert "too short" in meta["f2"]["error"] and math.isnan(meta["f2"]["vtc_threshold"]) and meta["f2"]["vtc_n_segments"] == 0
+    raw = [r for f in sorted((out / "vtc_raw").glob("shard_*.parquet")) for r in pq.read_table(f).to_pylist()]
+    merged_t = [pq.read_table(f) for f in sorted((out / "vtc_merged").glob("shard_*.parquet"))]
+    assert pq.read_table(out / "vtc_raw" / "shard_0.parquet").schema.names == ["uid", "onset", "offset", "duration", "label"]
+    assert pq.read_table(out / "vtc_meta" / "shard_0.parquet").schema.names == list(utils.META_SCHEMA.names)
+    # against the oracle run on the same files (confident frames decide; identical when masks are identical)
+    for uid in ("f0", "f1", "f3", "f4"):
+        wav = read_audio(tmp_path / "audio" / f"{uid}.wav")
+        ref = O.apply_model_on_waveform(weights, wav, 4.0)
+        m = O.apply_thresholds(ref, THR)
+        segs = O.intervals_to_segments(O.create_intervals(m), uid)
+        mine = sorted([r for r in raw if r["uid"] == uid], key=lambda r: (r["label"], r["onset"]))
+        assert meta[uid]["error"] == "" and meta[uid]["vtc_n_segments"] == len(mine)
+        if (ref.abs() > LOGIT_TOL).all():
+            assert mine == sorted(segs, key=lambda r: (r["label"], r["onset"]))
+            want = O.vtc_meta_row(uid, 0.5, segs, *O.sigmoid_summary(ref))
+            for k, v in want.items():
+                if k in ("vtc_max_sigmoid", "vtc_mean_sigmoid"):      # sigmoid' <= 1/4 -> 2e-2 on logits is 5e-3 here
+                    assert abs(meta[uid][k] - v) <= LOGIT_TOL / 4 + 1e-4, (uid, k)
+                else:
+                    assert meta[uid][k] == v, (uid, k)
+    for t in merged_t:
+        want = utils.merge_segments(pq.read_table(out / "vtc_raw" / "shard_0.parquet"), 0.3, 0.1) if t is merged_t[0] else None
+        if want is not None:
+            assert t.to_pylist() == want.to_pylist()
+    saved = torch.load(out / "logits" / "f0-logits_dict_t.pt", weights_only=True)
+    assert list(saved) == list(O.DEFAULT_LABELS) and saved["FEM"].shape[0] == O.n_frames_for_samples(int(3.2 * 16000))
+    # resume: nothing is recomputed, outputs stay identical
+    before = (out / "vtc_raw" / "shard_0.parquet").read_bytes()
+    cli.main("ds", array_id=0, array_count=2, **common)
+    assert pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist() == pq.read_table(pa_buf(before)).to_pylist()
+    assert (tmp_path / "logs" / "benchmarks.jsonl").exists()
+
+
+def pa_buf(b):
+    import pyarrow as pa
+    return pa.BufferReader(b)

@@ -1,0 +1,313 @@
+"""CPU: host-side mirror of the reference interface (no GPU compute), the C-ABI library's exports,
+and the N>1 sharding path over gloo (world_size 2)."""
+
+import ctypes
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+import torch
+
+from oracle import vtc_oracle as O
+from vtc_amd import lib, synth, utils
+from vtc_amd.core import intervals as I
+from vtc_amd.core import metadata as M
+from vtc_amd.segma_compat import install_as_segma
+from vtc_amd.segma_compat.config import load_config
+from vtc_amd.segma_compat.inference import logit_bounds
+from vtc_amd.segma_compat.models import ConvSettings, Models, normalise_state_dict
+from vtc_amd.segma_compat.utils.conversions import frames_to_seconds
+from vtc_amd.segma_compat.utils.encoders import MultiLabelEncoder
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return json.loads((golden_dir / "golden_kat.json").read_text())
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "vtc_amd.h").read_text()
+    declared = set(re.findall(r"\b(vtc_[a-z_]+)\s*\(", header))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    so = lib.load()
+    for name in declared:
+        assert getattr(so, name) is not None
+
+
+def test_no_gpu_calls_fail_loudly_not_silently():
+    so = lib.load()
+    assert so.vtc_frames_for_samples(399) == 0 and so.vtc_frames_for_samples(400) == 1
+    assert so.vtc_frames_for_samples(64000) == 199 and so.vtc_frames_for_samples(160000) == 499
+    assert so.vtc_profile_class_name(2) == b"gemm_mfma"
+    if not torch.cuda.is_available():
+        spec = lib.VtcSpec(abi_version=lib.ABI_VERSION, n_labels=4, window_samples=64000, max_batch=1, mfma_dtype=1)
+        h = ctypes.c_void_p()
+        rc = so.vtc_create(ctypes.byref(spec), ctypes.byref(lib.VtcWeights()), 0, ctypes.byref(h))
+        assert rc == lib.ERR_NO_GPU and not h.value
+        assert b"HIP device" in so.vtc_last_error(None)
+        from vtc_amd.engine import VtcEngine
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            VtcEngine(synth.make_weights(0), 4, 4.0)
+
+
+def test_bad_spec_rejected():
+    so = lib.load()
+    h = ctypes.c_void_p()
+    spec = lib.VtcSpec(abi_version=99, n_labels=4, window_samples=64000, max_batch=1, mfma_dtype=1)
+    assert so.vtc_create(ctypes.byref(spec), ctypes.byref(lib.VtcWeights()), 0, ctypes.byref(h)) == lib.ERR_ARG
+    spec = lib.VtcSpec(abi_version=lib.ABI_VERSION, n_labels=4, window_samples=200000, max_batch=1, mfma_dtype=1)
+    assert so.vtc_create(ctypes.byref(spec), ctypes.byref(lib.VtcWeights()), 0, ctypes.byref(h)) == lib.ERR_ARG
+    assert b"frames" in so.vtc_last_error(None)
+
+
+# ------------------------------------------------------------------ weights / synth
+def test_synth_weights_equal_oracle_weights():
+    a, b = synth.make_weights(seed=5), O.make_weights(seed=5)
+    assert set(a) == set(b)
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k].numpy(), rtol=2e-6, atol=1e-7, err_msg=k)
+
+
+def test_synth_audio_is_seeded_and_bounded():
+    x, y = synth.synth_audio(2.0, seed=3), synth.synth_audio(2.0, seed=3)
+    assert x.dtype == np.float32 and len(x) == 32000 and np.array_equal(x, y)
+    assert np.abs(x).max() < 1.0 and not np.array_equal(x, synth.synth_audio(2.0, seed=4))
+
+
+# ------------------------------------------------------------------ segma surface
+def test_conv_settings_and_encoder():
+    cs = ConvSettings()
+    assert cs.rf_step == 320 and cs.rf_size == 400
+    assert [cs.n_windows(n) for n in (399, 400, 4800, 64000, 160000)] == [0, 1, 14, 199, 499]
+    enc = MultiLabelEncoder(labels=["FEM", "MAL", "KCHI", "OCH"])
+    assert enc.n_labels == 4 and enc.inv_transform(2) == "KCHI" and enc.transform("OCH") == 3
+    with pytest.raises(ValueError):
+        MultiLabelEncoder(labels=["A", "A"])
+    assert frames_to_seconds(16000) == 1.0
+
+
+def test_config_and_checkpoint_loading(tmp_path):
+    cfg_path = tmp_path / "config.yml"
+    cfg_path.write_text("model:\n  name: surgical_hydra\n  extra: 1\ndata:\n  classes: [KCHI, OCH, MAL, FEM]\n"
+                        "audio:\n  chunk_duration_s: 10\n  sample_rate: 16000\ntrain:\n  lr: 1e-3\n")
+    cfg = load_config(cfg_path)
+    assert cfg.data.classes == ["KCHI", "OCH", "MAL", "FEM"] and cfg.audio.chunk_duration_s == 10.0
+    assert cfg.model.name == "surgical_hydra" and cfg.engine.mfma_dtype == "f16"
+    enc = MultiLabelEncoder(labels=cfg.data.classes)
+    m = Models[cfg.model.name].load_from_checkpoint(checkpoint_path="synthetic:3", label_encoder=enc, config=cfg, train=False)
+    assert m.eval() is m and m.to("cpu") is m and m.conv_settings.rf_step == 320
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.engine(10.0, 4)
+    # wrapped Lightning-style checkpoint, safe loader
+    sd = {"model.wav_encoder." + k: torch.from_numpy(v) for k, v in synth.make_weights(1).items() if not k.startswith("head.")}
+    sd["model.classifier.weight"] = torch.zeros(4, 768)
+    sd["model.classifier.bias"] = torch.ones(4)
+    torch.save({"state_dict": sd}, tmp_path / "best.ckpt")
+    m2 = Models["whatever"].load_from_checkpoint(checkpoint_path=tmp_path / "best.ckpt", label_encoder=enc, config=cfg)
+    assert "feature_extractor.conv_layers.0.conv.weight" in m2.state_dict_host
+    assert tuple(m2.state_dict_host["head.weight"].shape) == (4, 768)
+    with pytest.raises(KeyError):
+        normalise_state_dict({"foo": np.zeros(3)}, 4)
+
+
+def test_install_as_segma_matches_reference_imports():
+    install_as_segma()
+    from segma.config import load_config as lc            # noqa: F401  (reference src/pipeline/vtc.py:41-47)
+    from segma.config.base import Config                  # noqa: F401
+    from segma.inference import apply_model_on_audio, apply_thresholds, create_intervals  # noqa: F401
+    from segma.models import Models as Ms                 # noqa: F401
+    from segma.utils.encoders import MultiLabelEncoder as E  # noqa: F401
+    from segma.utils.conversions import frames_to_seconds as f2s  # reference src/core/intervals.py:10
+    assert f2s(320) == 0.02
+
+
+def test_logit_bounds_reproduce_prob_space_thresholds():
+    """x >= lo  <=>  sigmoid_f32(x) >= p.  torch's CPU sigmoid differs by an ulp between its vector and tail
+    paths, so exact agreement is asserted away from the boundary and the boundary is pinned to <= 4 ulp."""
+    rng = np.random.default_rng(0)
+    for p in (0.5, 0.3, 0.71, 0.05, 0.999):
+        lo, hi = logit_bounds({"A": {"lower_bound": p, "upper_bound": 1.0}}, ["A"])
+        assert hi[0] == np.inf
+        exact = math.log(np.float32(p) / (1 - np.float64(np.float32(p))))
+        tol = 4 * np.spacing(np.float32(abs(exact))) + 4e-7 + 4 * np.spacing(np.float32(p)) / (p * (1 - p))
+        assert abs(lo[0] - exact) <= tol
+        xs = np.concatenate([rng.standard_normal(20000).astype(np.float32) * 3,
+                             (exact + rng.uniform(-1e-3, 1e-3, 20000)).astype(np.float32)])
+        xs = xs[np.abs(xs - lo[0]) > tol]
+        want = (torch.sigmoid(torch.from_numpy(xs)) >= torch.tensor(p, dtype=torch.float32)).numpy()
+        assert np.array_equal(xs >= lo[0], want)
+    lo, hi = logit_bounds({"A": {"lower_bound": 0.5, "upper_bound": 1.0}}, ["A"])
+    assert lo[0] < 0 and lo[0] > -1e-6          # sigmoid(0) == 0.5 exactly: logit 0 is active
+    lo, hi = logit_bounds({"A": {"lower_bound": 0.2, "upper_bound": 0.8}}, ["A"])
+    xs = np.round((rng.standard_normal(5000) * 2) * 1024) / 1024
+    xs = xs.astype(np.float32)
+    pr = torch.sigmoid(torch.from_numpy(xs))
+    want = ((pr >= torch.tensor(0.2)) & (pr <= torch.tensor(0.8))).numpy()
+    assert np.array_equal((xs >= lo[0]) & (xs <= hi[0]), want)
+
+
+# ------------------------------------------------------------------ intervals / metadata / utils
+def test_intervals_match_oracle_and_kat(kat):
+    for case in kat["segments"]:
+        iv = [tuple(i) for i in case["intervals"]]
+        assert I.intervals_to_segments(iv, case["uid"]) == case["rows"] == O.intervals_to_segments(iv, case["uid"])
+    # reference tests/test_intervals.py cases
+    assert I.merge_pairs([]) == []
+    assert I.merge_pairs([(0.0, 2.0), (1.0, 3.0), (5.0, 6.0)]) == [(0.0, 3.0), (5.0, 6.0)]
+    assert I.merge_pairs([(0.0, 1.0), (1.0, 2.0)]) == [(0.0, 2.0)]
+    assert I.merge_pairs([(0.0, 10.0), (2.0, 5.0)]) == [(0.0, 10.0)]
+    assert I.merge_pairs([(3.0, 4.0), (0.0, 1.0), (2.0, 3.5)]) == [(0.0, 1.0), (2.0, 4.0)]
+    assert I.total_duration([(0.0, 1.0), (3.0, 5.0)]) == 3.0
+    assert I.intervals_to_pairs([(0, 16000, "KCHI"), (8000, 24000, "FEM")]) == [(0.0, 1.5)]
+    assert I.intervals_to_segments([], "t") == []
+    rng = np.random.default_rng(2)
+    iv = [(int(a) * 320, int(a + b) * 320 + 400, "FEM") for a, b in zip(rng.integers(0, 10**6, 500), rng.integers(0, 300, 500))]
+    assert I.intervals_to_segments(iv, "u") == O.intervals_to_segments(iv, "u")
+
+
+def test_metadata_rows_match_reference_goldens(golden_dir):
+    g = json.loads((golden_dir / "golden_meta.json").read_text())
+    for case in g["meta_rows"]:
+        assert M.vtc_meta_row(*case["args"]) == case["row"]
+        assert list(M.vtc_meta_row(*case["args"])) == list(case["row"])   # same key order -> same column order
+    for case in g["error_rows"]:
+        row = M.vtc_error_row(*case["args"])
+        assert set(row) == set(case["row"])
+        for k, v in case["row"].items():
+            assert (math.isnan(row[k]) if v is None else row[k] == v)
+
+
+def test_shard_list(kat):
+    s = kat["shard"]
+    items = list(range(s["n"]))
+    assert [utils.shard_list(items, i, s["count"]) for i in range(s["count"])] == s["slices"]
+    for n in (0, 1, 7, 8, 9, 100):
+        for c in (1, 3, 8):
+            parts = [utils.shard_list(list(range(n)), i, c) for i in range(c)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+            assert parts == [O.shard_list(list(range(n)), i, c) for i in range(c)]
+    with pytest.raises(ValueError):
+        utils.shard_list([1], 3, 3)
+
+
+def test_balanced_shards_cover_and_balance():
+    rng = np.random.default_rng(0)
+    costs = np.exp(rng.uniform(0, np.log(57600), 500)).tolist()
+    items = [f"f{i}" for i in range(500)]
+    parts = utils.balanced_shards(items, costs, 8)
+    assert sorted(sum(parts, [])) == sorted(items)
+    loads = [sum(costs[int(x[1:])] for x in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.15
+    naive = [sum(costs[int(x[1:])] for x in utils.shard_list(items, i, 8)) for i in range(8)]
+    assert max(loads) <= max(naive)
+
+
+def _rows(kat_rows):
+    return [dict(uid=u, label=l, onset=a, offset=b, duration=round(b - a, 3)) for u, l, a, b in kat_rows]
+
+
+def test_merge_segments_kat_and_oracle(kat):
+    m = kat["merge"]
+    got = utils.merge_segments(utils.segments_table(_rows(m["rows"])), m["collar"], m["min_on"])
+    assert got.column_names == ["uid", "onset", "offset", "duration", "label"]
+    rows = got.to_pylist()
+    assert [[r["uid"], r["label"], r["onset"], r["offset"], r["duration"]] for r in rows] == m["expected"]
+    # randomised agreement with the oracle's loop restatement
+    rng = np.random.default_rng(1)
+    rnd = []
+    for uid in ("u1", "u2", "u3"):
+        for lab in ("FEM", "MAL", "KCHI", "OCH"):
+            t = 0.0
+            for _ in range(int(rng.integers(0, 60))):
+                t += float(rng.choice([0.02, 0.1, 0.29, 0.3, 0.31, 0.5, 2.0]))
+                d = float(rng.choice([0.02, 0.045, 0.085, 0.105, 0.5, 3.985]))
+                rnd.append(dict(uid=uid, label=lab, onset=round(t, 3), offset=round(t + d, 3), duration=round(d, 3)))
+                t += d * float(rng.choice([0.5, 1.0]))
+    rng.shuffle(rnd)
+    got = utils.merge_segments(utils.segments_table(rnd), 0.3, 0.1).to_pylist()
+    assert got == O.merge_segments(rnd, 0.3, 0.1)
+    empty = utils.segments_table([])
+    assert utils.merge_segments(empty).num_rows == 0
+
+
+def test_atomic_write_resume_and_manifest(tmp_path, monkeypatch):
+    rows = [M.vtc_meta_row("a", 0.5, [], 0.1, 0.05), M.vtc_error_row("b", "bad file")]
+    utils.atomic_write_parquet(utils.meta_table(rows), tmp_path / "vtc_meta" / "shard_0.parquet")
+    utils.atomic_write_parquet(utils.meta_table([M.vtc_meta_row("c", 0.5, [], 0.1, 0.05)]), tmp_path / "vtc_meta" / "shard_1.parquet")
+    assert not list((tmp_path / "vtc_meta").glob("*.tmp"))
+    assert utils.load_completed_ids(tmp_path / "vtc_meta", "uid", "shard_*.parquet") == {"a", "b", "c"}   # error rows count
+    assert utils.load_completed_ids(tmp_path / "nope") == set()
+    t = pq.read_table(tmp_path / "vtc_meta" / "shard_0.parquet")
+    assert t.schema.names == list(utils.META_SCHEMA.names)
+    assert pq.ParquetFile(tmp_path / "vtc_meta" / "shard_0.parquet").metadata.row_group(0).column(0).compression == "ZSTD"
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "manifests" / "ds.csv").write_text("path,extra\n/x/a.wav,1\n/x/b.wav,2\n/x/c.wav,3\n")
+    paths = utils.get_dataset_paths("ds")
+    assert paths.manifest == Path("manifests/ds.csv") and paths.output == Path("output/ds")
+    man = utils.load_manifest(paths.manifest)
+    assert utils.manifest_paths(man) == ["/x/a.wav", "/x/b.wav", "/x/c.wav"]
+    assert utils.sample_manifest(man, None).num_rows == 3 and utils.sample_manifest(man, 2).num_rows == 2
+    assert utils.sample_manifest(man, 2).equals(utils.sample_manifest(man, 2))
+    with pytest.raises(FileNotFoundError):
+        utils.get_dataset_paths("missing")
+    rec = utils.log_benchmark("vtc", "ds", 3, 1.5, total_bytes=3000, extra={"shard_id": 0})
+    assert rec["bytes_per_second"] == 2000.0 and json.loads((tmp_path / "logs/benchmarks.jsonl").read_text())["step"] == "vtc"
+
+
+def test_audio_reader(tmp_path):
+    from vtc_amd.audio import read_audio, write_wav
+    from scipy.io import wavfile
+    x = synth.synth_audio(0.5, seed=1)
+    write_wav(tmp_path / "a.wav", x)
+    y = read_audio(tmp_path / "a.wav")
+    assert y.dtype == np.float32 and len(y) == 8000 and np.abs(y - x).max() <= 1.0 / 32768 + 1e-7
+    st = np.stack([x, -x], axis=1)
+    wavfile.write(tmp_path / "st.wav", 16000, (st * 32767).astype(np.int16))
+    assert np.abs(read_audio(tmp_path / "st.wav")).max() <= 1e-4          # channels averaged
+    wavfile.write(tmp_path / "r8.wav", 8000, (x[::2] * 32767).astype(np.int16))
+    assert abs(len(read_audio(tmp_path / "r8.wav")) - 8000) <= 1          # resampled to 16 kHz
+    with pytest.raises(ValueError):
+        read_audio(tmp_path / "x.mp3")
+
+
+# ------------------------------------------------------------------ N > 1 (gloo, world_size 2)
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["REPO"])
+from vtc_amd import dist, utils
+rank, world, _ = dist.init("gloo")
+items = [f"f{i}" for i in range(11)]
+mine = utils.shard_list(items, rank, world)
+dist.barrier()
+slowest = dist.max_over_ranks(1.0 + rank)
+total = dist.sum_over_ranks(len(mine))
+print(json.dumps({"rank": rank, "mine": mine, "slowest": slowest, "total": total}))
+dist.shutdown()
+"""
+
+
+def test_two_rank_sharding_over_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["mine"] + outs[1]["mine"] == [f"f{i}" for i in range(11)]
+    assert not set(outs[0]["mine"]) & set(outs[1]["mine"])
+    assert all(o["slowest"] == 2.0 and o["total"] == 11 for o in outs)

@@ -1,0 +1,32 @@
+"""Per-file VTC metadata rows (schema of the reference's src/core/metadata.py:12-50, which downstream
+readers depend on: src/pipeline/package.py:68-77, dataloader/adapters/vtc.py:97-126)."""
+
+from __future__ import annotations
+
+import json
+import math
+
+META_COLUMNS = ("uid", "vtc_threshold", "vtc_speech_dur", "vtc_n_segments", "vtc_label_counts",
+                "vtc_max_sigmoid", "vtc_mean_sigmoid", "error")
+
+
+def vtc_error_row(uid: str, error: str) -> dict:
+    """Row of a file whose inference raised: NaN statistics, zero segments, the message in `error`."""
+    return {
+        "vtc_threshold": math.nan, "vtc_speech_dur": 0.0, "vtc_n_segments": 0, "vtc_label_counts": "{}",
+        "vtc_max_sigmoid": math.nan, "vtc_mean_sigmoid": math.nan, "error": error, "uid": uid,
+    }
+
+
+def vtc_meta_row(uid: str, threshold: float, segments: list, max_sigmoid: float, mean_sigmoid: float) -> dict:
+    """Row of a processed file: total speech seconds (3 dp), segment count and per-label counts as JSON."""
+    per_label: dict = {}
+    total = 0.0
+    for seg in segments:
+        total += seg["duration"]
+        per_label[seg["label"]] = per_label.get(seg["label"], 0) + 1
+    return {
+        "uid": uid, "vtc_threshold": threshold, "vtc_speech_dur": round(total, 3),
+        "vtc_n_segments": len(segments), "vtc_label_counts": json.dumps(per_label),
+        "vtc_max_sigmoid": max_sigmoid, "vtc_mean_sigmoid": mean_sigmoid, "error": "",
+    }

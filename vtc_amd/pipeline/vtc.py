@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""VTC inference step, MI355X-native.  CLI-compatible with the reference's `python -m src.pipeline.vtc`
+(/root/reference/src/pipeline/vtc.py:422-497): same positional `dataset`, same flags, same outputs
+
+    output/{dataset}/vtc_raw/shard_{id}.parquet      uid, onset, offset, duration, label
+    output/{dataset}/vtc_merged/shard_{id}.parquet   same columns after collar merge
+    output/{dataset}/vtc_meta/shard_{id}.parquet     per-file metadata (core/metadata.py)
+    output/{dataset}/logits/{uid}-logits_dict_t.pt   [--save_logits]
+
+and the same resume rule (a uid present in ANY vtc_meta/shard_*.parquet is skipped, vtc.py:158-173).
+
+What differs is where the work runs: audio decode is prefetched on host threads while the GPU works, the
+whole forward runs in libvtc_amd.so, and threshold -> run-length decoding + the sigmoid summary happen on
+the GPU before anything is copied back (the reference does `.cpu()` first, vtc.py:252-281).
+
+Usage:
+    python -m vtc_amd.pipeline.vtc chunks30 --checkpoint VTC-2.0/model/best.ckpt
+    python -m vtc_amd.pipeline.vtc chunks30 --array_id 3 --array_count 8     # one of 8 GPU workers
+"""
+
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pyarrow.parquet as pq
+import torch
+
+from ..audio import read_audio
+from ..core.intervals import intervals_to_segments
+from ..core.metadata import vtc_error_row, vtc_meta_row
+from ..engine import RF_SIZE
+from ..segma_compat.config import load_config
+from ..segma_compat.config.base import Config
+from ..segma_compat.inference import logit_bounds
+from ..segma_compat.models import Models
+from ..segma_compat.utils.encoders import MultiLabelEncoder
+from ..utils import (SEGMENT_SCHEMA, add_sample_argument, atomic_write_parquet, get_dataset_paths, hhmmss,
+                     balanced_shards, load_completed_ids, load_manifest, log_benchmark, manifest_paths, merge_segments, meta_table,
+                     sample_manifest, segments_table, set_seeds, shard_list)
+
+logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
+logger = logging.getLogger("vtc")
+
+# VRAM -> windows per forward pass; same table as the reference (src/pipeline/resources.py:180-188).
+_BATCH_TABLE = [(80, 512), (48, 256), (32, 192), (24, 128), (16, 64), (0, 32)]
+
+
+def recommend_vtc_batch_size(vram_gb: float) -> int:
+    for min_vram, bs in _BATCH_TABLE:
+        if vram_gb >= min_vram:
+            return bs
+    return 32
+
+
+def _drop_uids(table: pa.Table, uids: set) -> pa.Table:
+    if table.num_rows == 0 or not uids:
+        return table
+    mask = pc.invert(pc.is_in(table.column("uid"), value_set=pa.array(sorted(uids), pa.string())))
+    return table.filter(mask)
+
+
+def _unique_rows(table: pa.Table) -> pa.Table:
+    if table.num_rows == 0:
+        return table
+    return table.group_by(table.column_names, use_threads=False).aggregate([]).select(table.column_names)
+
+
+def _unique_by_uid_keep_last(table: pa.Table) -> pa.Table:
+    uids = table.column("uid").to_pylist()
+    last = {}
+    for i, u in enumerate(uids):
+        last[u] = i
+    if len(last) == len(uids):
+        return table
+    return table.take(pa.array(sorted(last.values())))
+
+
+def process_file(engine, wav: np.ndarray, uid: str, threshold: float, labels, batch_size: int, save_to: Path | None):
+    """One file through the fused GPU path -> (segment rows, meta row)."""
+    if wav.shape[0] < RF_SIZE:
+        raise ValueError(f"audio too short: {wav.shape[0]} samples < receptive field {RF_SIZE}")
+    host = torch.from_numpy(wav)
+    gpu = host.pin_memory().to(engine.device, non_blocking=True) if host.numel() >= (1 << 20) else host.to(engine.device)
+    logits = engine.infer_waveform(gpu, batch_size)
+    lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
+    starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
+    if save_to is not None:
+        cpu = logits.cpu()
+        torch.save({labels[j]: cpu[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
+    intervals = [(int(s), int(e), labels[int(k)]) for s, e, k in zip(starts, ends, lab)]
+    segs = intervals_to_segments(intervals, uid)
+    max_sig = round(float(torch.sigmoid(torch.tensor(max_logit, dtype=torch.float32)).item()), 4)
+    return segs, vtc_meta_row(uid, threshold, segs, max_sig, round(float(mean_sig), 4))
+
+
+def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
+         threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 0,
+         save_logits: bool = False, device: str = "cuda", array_id: int | None = None,
+         array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False):
+    set_seeds(42)
+    if device != "cuda":
+        raise SystemExit(f"vtc_amd runs on ROCm GPUs only (--device {device} requested); it has no CPU path")
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm GPU visible; vtc_amd has no CPU path")
+    dev_index = torch.cuda.current_device()
+    if batch_size <= 0:
+        props = torch.cuda.get_device_properties(dev_index)
+        batch_size = recommend_vtc_batch_size(props.total_memory // (1024 ** 3))
+        logger.info(f"Auto batch_size={batch_size} for {props.name}")
+
+    paths = get_dataset_paths(dataset)
+    logger.info(f"Dataset: {dataset}")
+    logger.info(f"  manifest  : {paths.manifest}")
+    logger.info(f"  output    : {paths.output}")
+    logger.info(f"  threshold : {threshold}")
+    logger.info(f"  batch_size: {batch_size}")
+
+    manifest = sample_manifest(load_manifest(paths.manifest), sample)
+    resolved = manifest_paths(manifest)
+    file_ids = [Path(p).stem for p in resolved]
+    uid_to_path = dict(zip(file_ids, resolved))
+    if array_id is not None and array_count is not None:
+        if balance:
+            # duration-balanced shards for skewed manifests (every worker derives the same assignment)
+            costs = []
+            for p in resolved:
+                try:
+                    costs.append(os.path.getsize(p))
+                except OSError:
+                    costs.append(0)
+            file_ids = balanced_shards(file_ids, costs, array_count)[array_id]
+        else:
+            file_ids = shard_list(file_ids, array_id, array_count)
+        logger.info(f"Shard {array_id}/{array_count - 1}: {len(file_ids)} files")
+    shard_id = array_id if array_id is not None else 0
+
+    # ---- resume: skip files already processed by ANY shard
+    meta_dir = paths.output / "vtc_meta"
+    meta_path = meta_dir / f"shard_{shard_id}.parquet"
+    completed = load_completed_ids(meta_dir, id_column="uid", pattern="shard_*.parquet")
+    prev_meta = pq.read_table(meta_path) if meta_path.exists() else None
+    todo = [u for u in file_ids if u not in completed]
+    if len(todo) < len(file_ids):
+        logger.info(f"Resume: {len(file_ids) - len(todo)} done, {len(todo)} remaining")
+    if not todo and not file_ids:
+        logger.info("No files to process.")
+        return
+
+    # ---- model
+    if Path(config).exists():
+        model_config: Config = load_config(config)
+    else:
+        logger.warning(f"config {config} not found; using built-in defaults (4 s windows, VTC_LABELS order)")
+        model_config = Config()
+    l_encoder = MultiLabelEncoder(labels=model_config.data.classes)
+    model = Models[model_config.model.name].load_from_checkpoint(
+        checkpoint_path=checkpoint, label_encoder=l_encoder, config=model_config, train=False)
+    model.eval()
+    model.to(torch.device("cuda", dev_index))
+    chunk_duration_s = model_config.audio.chunk_duration_s
+    engine = model.engine(chunk_duration_s, batch_size)
+    labels = l_encoder.labels
+
+    logits_dir = paths.output / "logits"
+    if save_logits:
+        logits_dir.mkdir(parents=True, exist_ok=True)
+
+    sizes = {}
+    for u in todo:
+        try:
+            sizes[u] = Path(uid_to_path[u]).stat().st_size
+        except OSError:
+            sizes[u] = 0
+    total_bytes = sum(sizes.values()) or 1
+    total = len(todo)
+    print(f"Shard {shard_id}: {total} files, {total_bytes / 1e9:.1f} GB", flush=True)
+
+    meta_rows, seg_rows = [], []
+    n_errors, bytes_done, audio_seconds = 0, 0, 0.0
+    t0 = last_log = time.time()
+    log_every = max(1, total // 20)
+    with ThreadPoolExecutor(max_workers=max(1, prefetch)) as pool:
+        pending = {}
+        nxt = 0
+
+        def top_up():
+            nonlocal nxt
+            while nxt < total and len(pending) < max(1, prefetch):
+                pending[nxt] = pool.submit(read_audio, uid_to_path[todo[nxt]])
+                nxt += 1
+
+        top_up()
+        for i, uid in enumerate(todo):
+            fut = pending.pop(i)
+            top_up()
+            try:
+                wav = fut.result()
+                with torch.no_grad():
+                    segs, row = process_file(engine, wav, uid, threshold, labels, batch_size,
+                                             logits_dir if save_logits else None)
+                audio_seconds += wav.shape[0] / 16000.0
+            except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
+                n_errors += 1
+                logger.warning(f"{uid}: {e}")
+                meta_rows.append(vtc_error_row(uid, str(e)))
+                continue
+            seg_rows.extend(segs)
+            meta_rows.append(row)
+            bytes_done += sizes.get(uid, 0)
+            now = time.time()
+            if (i + 1) % log_every == 0 or i + 1 == total or now - last_log >= 60:
+                rate = bytes_done / max(now - t0, 1e-9)
+                eta_s = (total_bytes - bytes_done) / rate if rate > 0 else 0
+                eta = f"{eta_s / 60:.0f}m" if eta_s < 3600 else f"{eta_s / 3600:.1f}h"
+                print(f"  VTC  {i + 1:>4}/{total}  {bytes_done / 1e9:.1f}/{total_bytes / 1e9:.1f} GB"
+                      f" ({100.0 * bytes_done / total_bytes:.0f}%)  ETA {eta}", flush=True)
+                last_log = now
+
+    # ---- merge with the shard's previous rows (resume), de-duplicate
+    new_meta = meta_table(meta_rows) if meta_rows else None
+    parts = []
+    if prev_meta is not None:
+        kept = _drop_uids(prev_meta, {r["uid"] for r in meta_rows}) if new_meta is not None else prev_meta
+        if kept.num_rows:
+            parts.append(kept.cast(new_meta.schema) if new_meta is not None else kept)
+    if new_meta is not None:
+        parts.append(new_meta)
+    meta_df = pa.concat_tables(parts) if parts else meta_table([])
+    before = meta_df.num_rows
+    meta_df = _unique_by_uid_keep_last(meta_df)
+    if meta_df.num_rows < before:
+        logger.warning(f"Dedup: removed {before - meta_df.num_rows} duplicate meta rows (shard {shard_id})")
+
+    new_seg = segments_table(seg_rows)
+    raw_path = paths.output / "vtc_raw" / f"shard_{shard_id}.parquet"
+    if raw_path.exists() and completed:
+        prev_seg = _drop_uids(pq.read_table(raw_path).cast(SEGMENT_SCHEMA), {r["uid"] for r in seg_rows})
+        seg_df = pa.concat_tables([t for t in (prev_seg, new_seg) if t.num_rows]) if (prev_seg.num_rows or new_seg.num_rows) else new_seg
+    else:
+        seg_df = new_seg
+    before = seg_df.num_rows
+    seg_df = _unique_rows(seg_df)
+    if seg_df.num_rows < before:
+        logger.warning(f"Dedup: removed {before - seg_df.num_rows} duplicate segment rows (shard {shard_id})")
+
+    # ---- outputs (tmp + rename, zstd)
+    atomic_write_parquet(meta_df, meta_path)
+    atomic_write_parquet(seg_df, raw_path)
+    merged_df = merge_segments(seg_df, min_duration_off_s, min_duration_on_s)
+    atomic_write_parquet(merged_df, paths.output / "vtc_merged" / f"shard_{shard_id}.parquet")
+
+    wall = time.time() - t0
+    print(flush=True)
+    logger.info("-" * 50)
+    logger.info(f"Shard {shard_id} complete")
+    logger.info(f"  Files     : {total - n_errors}/{total}  ({n_errors} errors)")
+    logger.info(f"  Threshold : {threshold}")
+    logger.info(f"  Segments  : {seg_df.num_rows:,} raw, {merged_df.num_rows:,} merged")
+    logger.info(f"  Wall time : {hhmmss(wall)}   ({audio_seconds / 3600.0 / max(wall, 1e-9):.3f} audio-hours/s)")
+    logger.info("-" * 50)
+    done_bytes = sum(os.path.getsize(uid_to_path[u]) for u in todo if os.path.exists(uid_to_path[u]))
+    log_benchmark(step="vtc", dataset=dataset, n_files=total, wall_seconds=wall, total_audio_seconds=audio_seconds,
+                  total_bytes=done_bytes, n_workers=1,
+                  extra={"device": torch.cuda.get_device_name(dev_index), "shard_id": shard_id,
+                         "mfma_dtype": model_config.engine.mfma_dtype})
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="VTC inference with fixed per-file thresholding (MI355X-native).",
+                                formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("dataset", help="Dataset name - used to derive manifests/, output/ and figures/ paths.")
+    p.add_argument("--config", default="VTC-2.0/model/config.yml", help="model config YAML")
+    p.add_argument("--checkpoint", default="VTC-2.0/model/best.ckpt",
+                   help="model checkpoint (.ckpt/.pt/.safetensors/.npz) or 'synthetic[:seed]'")
+    p.add_argument("--threshold", type=float, default=0.5, help="Sigmoid threshold (default: 0.5)")
+    p.add_argument("--min_duration_on_s", type=float, default=0.1, help="Remove segments shorter than this (0.1 s)")
+    p.add_argument("--min_duration_off_s", type=float, default=0.3, help="Merge same-label segments with gap <= this (0.3 s)")
+    p.add_argument("--batch_size", type=int, default=0, help="Windows per forward pass; 0 = from GPU memory")
+    p.add_argument("--save_logits", action="store_true", help="Save per-file logits to output/{dataset}/logits/")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu", "mps"], help="Only 'cuda' (ROCm) is supported")
+    p.add_argument("--array_id", type=int, help="Shard index (SLURM array task ID or launcher rank)")
+    p.add_argument("--array_count", type=int, help="Number of shards")
+    p.add_argument("--prefetch", type=int, default=4, help="audio files decoded ahead on host threads")
+    p.add_argument("--balance", action="store_true",
+                   help="shard by file size (longest-processing-time) instead of equal counts; all workers of a run "
+                        "must agree on this flag")
+    add_sample_argument(p)
+    return p
+
+
+if __name__ == "__main__":
+    main(**vars(build_parser().parse_args()))

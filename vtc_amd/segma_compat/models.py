@@ -1,0 +1,127 @@
+"""segma.models stand-in: `Models[name].load_from_checkpoint(...)` (reference src/pipeline/vtc.py:185-192).
+
+The returned object owns the weights on the host until `.to(device)`; the GPU engine (libvtc_amd.so) is
+created lazily for the (chunk_duration_s, batch_size) the first apply_model_on_audio call asks for.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import prod
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..engine import VtcEngine
+from .. import synth
+
+_ANCHOR = "feature_extractor.conv_layers.0.conv.weight"
+
+
+@dataclass(frozen=True)
+class ConvSettings:
+    """What `model.conv_settings` carries (reference src/pipeline/vtc.py:194; geometry from
+    src/analysis/chunk_artifact.py:43-57)."""
+    kernels: tuple = (10, 3, 3, 3, 3, 2, 2)
+    strides: tuple = (5, 2, 2, 2, 2, 2, 2)
+    paddings: tuple = (0, 0, 0, 0, 0, 0, 0)
+
+    @property
+    def rf_step(self) -> int:
+        return prod(self.strides)
+
+    @property
+    def rf_size(self) -> int:
+        return 1 + sum((k - 1) * prod(self.strides[:i]) for i, k in enumerate(self.kernels))
+
+    def n_windows(self, n_samples: int) -> int:
+        """Number of output frames for n_samples input samples."""
+        return 0 if n_samples < self.rf_size else (n_samples - self.rf_size) // self.rf_step + 1
+
+
+def _load_state_dict(path: Path) -> dict:
+    suf = path.suffix.lower()
+    if suf == ".safetensors":
+        from safetensors.numpy import load_file
+        return dict(load_file(str(path)))
+    if suf == ".npz":
+        with np.load(str(path), allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    obj = torch.load(str(path), map_location="cpu", weights_only=True)  # never unpickles code
+    if isinstance(obj, dict) and "state_dict" in obj:
+        obj = obj["state_dict"]   # Lightning layout
+    return dict(obj)
+
+
+def normalise_state_dict(sd: dict, n_labels: int) -> dict:
+    """Strip whatever wrapper prefix the checkpoint uses and locate the head (UNPINNED: segma's module
+    names are not in the reference tree; HF HubertModel names are what this build understands)."""
+    anchor = [k for k in sd if k.endswith(_ANCHOR)]
+    if not anchor:
+        raise KeyError(f"checkpoint has no '*{_ANCHOR}' tensor; not a HuBERT-style encoder")
+    prefix = anchor[0][: -len(_ANCHOR)]
+    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if "head.weight" not in out:
+        cands = [k for k, v in sd.items() if k.endswith("weight") and tuple(np.shape(v)) == (n_labels, 768)]
+        if len(cands) != 1:
+            raise KeyError("cannot identify the multi-label head ([n_labels, 768] weight) in the checkpoint")
+        out["head.weight"] = sd[cands[0]]
+        out["head.bias"] = sd[cands[0][: -len("weight")] + "bias"]
+    return out
+
+
+class VtcModel:
+    conv_settings = ConvSettings()
+
+    def __init__(self, state_dict: dict, label_encoder, config):
+        self.state_dict_host = state_dict
+        self.label_encoder = label_encoder
+        self.config = config
+        self.device = torch.device("cpu")
+        self._engines = {}
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, label_encoder, config, train: bool = False, **_):
+        if train:
+            raise NotImplementedError("vtc_amd is inference-only")
+        cp = str(checkpoint_path)
+        if cp.startswith("synthetic"):
+            seed = int(cp.split(":", 1)[1]) if ":" in cp else int(getattr(config.engine, "synthetic_seed", 0))
+            sd = synth.make_weights(seed=seed, n_labels=label_encoder.n_labels)
+        else:
+            sd = normalise_state_dict(_load_state_dict(Path(cp)), label_encoder.n_labels)
+        return cls(sd, label_encoder, config)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def engine(self, chunk_duration_s: float, batch_size: int, device=None) -> VtcEngine:
+        dev = torch.device(device) if device is not None else self.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"vtc_amd runs on ROCm GPUs only (requested device '{dev}'); there is no CPU path")
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        max_batch = int(getattr(self.config.engine, "max_batch", 0) or batch_size)
+        key = (round(float(chunk_duration_s), 6), max(max_batch, int(batch_size)), index)
+        if key not in self._engines:
+            for e in self._engines.values():
+                e.close()
+            self._engines.clear()
+            self._engines[key] = VtcEngine(self.state_dict_host, self.label_encoder.n_labels, chunk_duration_s,
+                                           max_batch=key[1], mfma_dtype=self.config.engine.mfma_dtype, device=index)
+        return self._engines[key]
+
+    def any_engine(self):
+        return next(iter(self._engines.values()), None)
+
+
+class _Registry(dict):
+    def __missing__(self, name):
+        return VtcModel   # every model name in a segma config maps onto the one encoder this build implements
+
+
+Models = _Registry(surgical_hydra=VtcModel, hydra=VtcModel)

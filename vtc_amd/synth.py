@@ -1,0 +1,96 @@
+"""Synthetic inputs for benchmarks and tests: seeded 16 kHz mono audio and seeded
+BabyHuBERT-shaped weights.  The real VTC-2.0 checkpoint (git-lfs submodule, reference .gitmodules:1-3)
+is not available offline; a real state dict can be passed to VtcEngine instead of these.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+SAMPLE_RATE = 16_000
+CONV_KERNELS = (10, 3, 3, 3, 3, 2, 2)   # reference: src/analysis/chunk_artifact.py:43
+LABELS = ("FEM", "MAL", "KCHI", "OCH")  # reference: src/core/__init__.py:7
+
+
+def synth_audio(duration_s: float, seed: int, dtype=np.float32) -> np.ndarray:
+    """3-6 amplitude-modulated harmonic voices (f0 100-400 Hz, random 0.2-3 s on/off) plus
+    low-passed noise at about -30 dBFS, so that logits cross zero often."""
+    rng = np.random.default_rng(seed)
+    n = int(round(duration_s * SAMPLE_RATE))
+    t = np.arange(n, dtype=np.float64) / SAMPLE_RATE
+    out = np.zeros(n, dtype=np.float64)
+    for _ in range(int(rng.integers(3, 7))):
+        f0 = rng.uniform(100.0, 400.0)
+        vib = 1.0 + 0.01 * np.sin(2 * np.pi * rng.uniform(3.0, 7.0) * t + rng.uniform(0, 2 * np.pi))
+        phase = 2 * np.pi * f0 * np.cumsum(vib) / SAMPLE_RATE
+        voice = np.zeros(n)
+        for h in range(1, 6):
+            voice += np.sin(h * phase + rng.uniform(0, 2 * np.pi)) / h
+        # on/off gate with 10 ms ramps
+        gate = np.zeros(n)
+        pos, on = 0, bool(rng.integers(0, 2))
+        while pos < n:
+            seg = int(rng.uniform(0.2, 3.0) * SAMPLE_RATE)
+            if on:
+                gate[pos: pos + seg] = 1.0
+            pos += seg
+            on = not on
+        ramp = np.ones(160) / 160.0
+        gate = np.convolve(gate, ramp, mode="same")
+        am = 0.6 + 0.4 * np.sin(2 * np.pi * rng.uniform(3.0, 8.0) * t + rng.uniform(0, 2 * np.pi))
+        out += rng.uniform(0.3, 1.0) * voice * gate * am
+    peak = np.abs(out).max()
+    if peak > 0:
+        out *= 0.5 / peak
+    noise = rng.standard_normal(n)
+    # one-pole low-pass -> "pink-ish"
+    from scipy.signal import lfilter
+    noise = lfilter([1.0], [1.0, -0.95], noise)
+    noise *= 10 ** (-30 / 20) / (np.sqrt(np.mean(noise ** 2)) + 1e-12)
+    return (out + noise).astype(dtype)
+
+
+def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0) -> dict:
+    """Seeded random weights under HF HubertModel state-dict names (+ head.weight / head.bias).
+    numpy PCG64 -> identical tensors on every machine.  Scales are 1/sqrt(fan_in) so every branch
+    carries signal (a harder numerical case than HF's 0.02 init)."""
+    rng = np.random.default_rng(seed)
+
+    def randn(*shape, std=1.0):
+        return rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+
+    w = {}
+    cin = 1
+    for i, k in enumerate(CONV_KERNELS):
+        w[f"feature_extractor.conv_layers.{i}.conv.weight"] = randn(512, cin, k, std=(2.0 / (cin * k)) ** 0.5)
+        cin = 512
+    w["feature_extractor.conv_layers.0.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
+    w["feature_extractor.conv_layers.0.layer_norm.bias"] = randn(512, std=0.1)
+    w["feature_projection.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
+    w["feature_projection.layer_norm.bias"] = randn(512, std=0.1)
+    w["feature_projection.projection.weight"] = randn(768, 512, std=512 ** -0.5)
+    w["feature_projection.projection.bias"] = randn(768, std=0.02)
+    v = randn(768, 48, 128, std=(48 * 128) ** -0.5)
+    w["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
+    w["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (
+        np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+        * (1.0 + randn(1, 1, 128, std=0.1)))
+    w["encoder.pos_conv_embed.conv.bias"] = randn(768, std=0.02)
+    w["encoder.layer_norm.weight"] = 1.0 + randn(768, std=0.1)
+    w["encoder.layer_norm.bias"] = randn(768, std=0.1)
+    for l in range(12):
+        p = f"encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[p + f"attention.{nm}.weight"] = randn(768, 768, std=768 ** -0.5)
+            w[p + f"attention.{nm}.bias"] = randn(768, std=0.02)
+        w[p + "layer_norm.weight"] = 1.0 + randn(768, std=0.1)
+        w[p + "layer_norm.bias"] = randn(768, std=0.1)
+        w[p + "feed_forward.intermediate_dense.weight"] = randn(3072, 768, std=768 ** -0.5)
+        w[p + "feed_forward.intermediate_dense.bias"] = randn(3072, std=0.02)
+        w[p + "feed_forward.output_dense.weight"] = randn(768, 3072, std=3072 ** -0.5)
+        w[p + "feed_forward.output_dense.bias"] = randn(768, std=0.02)
+        w[p + "final_layer_norm.weight"] = 1.0 + randn(768, std=0.1)
+        w[p + "final_layer_norm.bias"] = randn(768, std=0.1)
+    w["head.weight"] = randn(n_labels, 768, std=logit_std * 768 ** -0.5)
+    w["head.bias"] = randn(n_labels, std=0.5)
+    return w

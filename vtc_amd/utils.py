@@ -1,0 +1,298 @@
+"""Manifest, sharding, resume and output helpers of the VTC step.
+
+Behavioural mirror of the parts of the reference's src/utils.py that `src/pipeline/vtc.py` calls
+(polars is not available here; tables are pyarrow, columns are numpy):
+  shard_list .............. src/utils.py:271-285
+  load_manifest ........... src/utils.py:293-320
+  sample_manifest ......... src/utils.py:229-268
+  merge_segments .......... src/utils.py:323-390
+  atomic_write_parquet .... src/utils.py:393-401
+  log_benchmark ........... src/utils.py:434-471
+  load_completed_ids ...... src/utils.py:497-526
+  get_dataset_paths ....... src/utils.py:72-175
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import platform
+import random
+import socket
+import time
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+
+MANIFEST_EXTENSIONS = [".parquet", ".csv", ".tsv", ".json", ".jsonl"]
+BENCHMARK_LOG = Path("logs/benchmarks.jsonl")
+
+SEGMENT_SCHEMA = pa.schema([("uid", pa.string()), ("onset", pa.float64()), ("offset", pa.float64()),
+                            ("duration", pa.float64()), ("label", pa.string())])
+META_SCHEMA = pa.schema([("uid", pa.string()), ("vtc_threshold", pa.float64()), ("vtc_speech_dur", pa.float64()),
+                         ("vtc_n_segments", pa.int64()), ("vtc_label_counts", pa.string()),
+                         ("vtc_max_sigmoid", pa.float64()), ("vtc_mean_sigmoid", pa.float64()), ("error", pa.string())])
+
+
+def set_seeds(seed: int = 42) -> None:
+    random.seed(seed)
+    np.random.seed(seed)
+    try:
+        import torch
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+    except ImportError:
+        pass
+
+
+def hhmmss(seconds: float) -> str:
+    s = int(seconds)
+    return f"{s // 3600:02d}:{s % 3600 // 60:02d}:{s % 60:02d}"
+
+
+# --------------------------------------------------------------------------- paths / manifest
+@dataclass
+class DatasetPaths:
+    dataset: str
+    manifest: Path
+    output: Path
+    figures: Path
+
+
+def resolve_manifest(arg: str) -> Path:
+    """An explicit manifest path, or a bare dataset name looked up as manifests/{name}.<ext>
+    (.csv wins when several formats exist)."""
+    p = Path(arg)
+    if "/" in arg or "\\" in arg or p.suffix.lower() in MANIFEST_EXTENSIONS:
+        if not p.exists():
+            raise FileNotFoundError(f"Manifest file not found: {p.resolve()}")
+        if p.suffix.lower() not in MANIFEST_EXTENSIONS:
+            raise ValueError(f"Unsupported manifest format '{p.suffix}'. Supported: {', '.join(MANIFEST_EXTENSIONS)}")
+        return p
+    root = Path("manifests")
+    if not root.is_dir():
+        raise FileNotFoundError(f"No 'manifests/' directory found and '{arg}' is not a path to an existing file.")
+    hits = [root / f"{arg}{ext}" for ext in MANIFEST_EXTENSIONS if (root / f"{arg}{ext}").is_file()]
+    if not hits:
+        raise FileNotFoundError(f"No manifest found for dataset '{arg}' (searched manifests/{arg}.<ext>)")
+    if len(hits) == 1:
+        return hits[0]
+    csv = [h for h in hits if h.suffix.lower() == ".csv"]
+    if len(csv) == 1:
+        return csv[0]
+    raise ValueError(f"Ambiguous: multiple manifests match '{arg}': {', '.join(map(str, hits))}")
+
+
+def get_dataset_paths(dataset: str) -> DatasetPaths:
+    return DatasetPaths(dataset=dataset, manifest=resolve_manifest(dataset), output=Path("output") / dataset,
+                        figures=Path("figures") / dataset)
+
+
+def load_manifest(path: Path) -> pa.Table:
+    suffix = Path(path).suffix.lower()
+    if suffix == ".parquet":
+        return pq.read_table(path)
+    if suffix in (".csv", ".tsv"):
+        from pyarrow import csv as pacsv
+        return pacsv.read_csv(path, parse_options=pacsv.ParseOptions(delimiter="\t" if suffix == ".tsv" else ","))
+    if suffix == ".jsonl":
+        from pyarrow import json as pajson
+        return pajson.read_json(path)
+    if suffix == ".json":
+        with open(path) as f:
+            return pa.Table.from_pylist(json.load(f))
+    raise ValueError(f"Unsupported manifest format '{suffix}'. Supported: {', '.join(MANIFEST_EXTENSIONS)}")
+
+
+def manifest_paths(table: pa.Table, column: str = "path") -> list[str]:
+    if column not in table.column_names:
+        raise KeyError(f"manifest has no '{column}' column (columns: {table.column_names})")
+    return [p for p in table.column(column).to_pylist() if p is not None]
+
+
+def sample_manifest(table: pa.Table, sample, seed: int = 42) -> pa.Table:
+    """None -> unchanged; int >= 1 -> that many rows; float in (0,1) -> that fraction.  Deterministic for a
+    seed (the reference uses polars' sampler, so the chosen subset differs from it; the contract is
+    'fixed seed -> fixed subset')."""
+    if sample is None:
+        return table
+    n = table.num_rows
+    if isinstance(sample, float) and 0 < sample < 1:
+        keep = max(1, int(round(n * sample)))
+    elif isinstance(sample, (int, float)) and sample >= 1:
+        keep = int(sample)
+    else:
+        raise ValueError(f"Invalid --sample value: {sample!r}.")
+    if keep >= n:
+        return table
+    idx = np.sort(np.random.default_rng(seed).permutation(n)[:keep])
+    return table.take(pa.array(idx))
+
+
+def shard_list(items: list, array_id: int, array_count: int) -> list:
+    """Contiguous slice `array_id` of `array_count`; the first len % count shards get one extra item."""
+    if array_count < 1 or not (0 <= array_id < array_count):
+        raise ValueError(f"array_id {array_id} not in [0, {array_count})")
+    base, extra = divmod(len(items), array_count)
+    lo = array_id * base + min(array_id, extra)
+    return items[lo: lo + base + (1 if array_id < extra else 0)]
+
+
+def balanced_shards(items: list, costs: list, n_shards: int) -> list[list]:
+    """Longest-processing-time assignment by cost (e.g. file size) for skewed manifests; within a shard the
+    manifest order is kept.  Not in the reference (it slices by count); used by vtc_amd.launcher."""
+    order = sorted(range(len(items)), key=lambda i: (-costs[i], i))
+    load = [0.0] * n_shards
+    owner = [0] * len(items)
+    for i in order:
+        s = min(range(n_shards), key=lambda k: (load[k], k))
+        owner[i] = s
+        load[s] += costs[i]
+    return [[items[i] for i in range(len(items)) if owner[i] == s] for s in range(n_shards)]
+
+
+# --------------------------------------------------------------------------- segments
+def segments_table(rows: list[dict]) -> pa.Table:
+    cols = {name: [r[name] for r in rows] for name in SEGMENT_SCHEMA.names}
+    return pa.table(cols, schema=SEGMENT_SCHEMA)
+
+
+def meta_table(rows: list[dict]) -> pa.Table:
+    cols = {name: [r[name] for r in rows] for name in META_SCHEMA.names}
+    return pa.table(cols, schema=META_SCHEMA)
+
+
+def merge_segments(table: pa.Table, min_duration_off_s: float = 0.1, min_duration_on_s: float = 0.1) -> pa.Table:
+    """Collar merge + minimum duration, per (uid, label).
+
+    Sorted by onset, a segment opens a new group when its onset exceeds the running maximum of all earlier
+    offsets in the partition by more than the collar; a group becomes (min onset, max offset), both rounded
+    to 3 decimals, duration = round(offset - onset, 3); groups shorter than min_duration_on_s are dropped.
+    Result ordered by (uid, label, onset)."""
+    if table.num_rows == 0:
+        return table
+    has_label = "label" in table.column_names
+    uid = np.asarray(table.column("uid").to_pylist(), dtype=object)
+    lab = np.asarray(table.column("label").to_pylist(), dtype=object) if has_label else None
+    onset = table.column("onset").to_numpy(zero_copy_only=False).astype(np.float64)
+    offset = table.column("offset").to_numpy(zero_copy_only=False).astype(np.float64)
+
+    uid_names, uid_code = np.unique(uid.astype(str), return_inverse=True)
+    if has_label:
+        lab_names, lab_code = np.unique(lab.astype(str), return_inverse=True)
+        part = uid_code.astype(np.int64) * len(lab_names) + lab_code
+    else:
+        part = uid_code.astype(np.int64)
+    order = np.lexsort((onset, part))           # stable: ties keep input order, like a stable sort
+    part, onset, offset = part[order], onset[order], offset[order]
+
+    n = len(part)
+    part_start = np.ones(n, dtype=bool)
+    part_start[1:] = part[1:] != part[:-1]
+    starts = np.flatnonzero(part_start)
+    ends = np.append(starts[1:], n)
+    prev_max = np.zeros(n, dtype=np.float64)     # first row of a partition compares against 0.0
+    for a, b in zip(starts, ends):
+        if b - a > 1:
+            prev_max[a + 1: b] = np.maximum.accumulate(offset[a: b - 1])
+    group_start = part_start | (onset > prev_max + min_duration_off_s)
+    gs = np.flatnonzero(group_start)
+    g_on = np.round(np.minimum.reduceat(onset, gs), 3)
+    g_off = np.round(np.maximum.reduceat(offset, gs), 3)
+    g_dur = np.round(g_off - g_on, 3)
+    g_part = part[gs]
+    keep = g_dur >= min_duration_on_s
+    g_on, g_off, g_dur, g_part = g_on[keep], g_off[keep], g_dur[keep], g_part[keep]
+    final = np.lexsort((g_on, g_part))
+    g_on, g_off, g_dur, g_part = g_on[final], g_off[final], g_dur[final], g_part[final]
+    cols = {}
+    if has_label:
+        cols["uid"] = pa.array(uid_names[g_part // len(lab_names)].tolist(), pa.string())
+    else:
+        cols["uid"] = pa.array(uid_names[g_part].tolist(), pa.string())
+    cols["onset"], cols["offset"], cols["duration"] = pa.array(g_on), pa.array(g_off), pa.array(g_dur)
+    if has_label:
+        cols["label"] = pa.array(lab_names[g_part % len(lab_names)].tolist(), pa.string())
+    return pa.table(cols)
+
+
+# --------------------------------------------------------------------------- outputs / resume
+def atomic_write_parquet(table: pa.Table, path, compression: str = "zstd") -> None:
+    """Write to <name>.parquet.tmp then rename, so readers never see a partial shard."""
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    tmp = path.with_suffix(".parquet.tmp")
+    pq.write_table(table, tmp, compression=compression)
+    os.replace(tmp, path)
+
+
+def load_completed_ids(meta_dir: Path, id_column: str = "uid", pattern: str = "*.parquet") -> set:
+    """uids present in any metadata parquet under meta_dir (error rows included: errored files are not
+    retried, as in the reference)."""
+    meta_dir = Path(meta_dir)
+    if meta_dir.is_file():
+        return set(pq.read_table(meta_dir, columns=[id_column]).column(id_column).to_pylist())
+    if not meta_dir.is_dir():
+        return set()
+    done: set = set()
+    for f in sorted(meta_dir.glob(pattern)):
+        done.update(pq.read_table(f, columns=[id_column]).column(id_column).to_pylist())
+    return done
+
+
+def _gpu_name() -> str:
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.get_device_name(0)
+    except Exception:
+        pass
+    return ""
+
+
+def log_benchmark(step: str, dataset: str, n_files: int, wall_seconds: float, total_audio_seconds: float = 0.0,
+                  total_bytes: int = 0, n_workers: int | None = None, extra: dict | None = None) -> dict:
+    """Append one JSON record to logs/benchmarks.jsonl (same keys as the reference's records)."""
+    rec = {
+        "timestamp": time.strftime("%Y-%m-%dT%H:%M:%S%z"), "step": step, "dataset": dataset, "n_files": n_files,
+        "wall_seconds": round(wall_seconds, 2), "total_audio_seconds": round(total_audio_seconds, 2),
+        "total_bytes": total_bytes,
+        "files_per_second": round(n_files / wall_seconds, 2) if wall_seconds > 0 else 0,
+        "bytes_per_second": round(total_bytes / wall_seconds, 2) if wall_seconds > 0 and total_bytes > 0 else 0,
+        "hardware": {"hostname": socket.gethostname(), "cpu_count": os.cpu_count() or 0, "n_workers": n_workers,
+                     "gpu": _gpu_name(), "platform": platform.platform()},
+    }
+    if extra:
+        rec["extra"] = extra
+    BENCHMARK_LOG.parent.mkdir(parents=True, exist_ok=True)
+    with open(BENCHMARK_LOG, "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    return rec
+
+
+# --------------------------------------------------------------------------- argparse
+def _parse_sample(value: str):
+    try:
+        if "." in value:
+            f = float(value)
+            if 0 < f < 1:
+                return f
+            raise ValueError
+        n = int(value)
+        if n < 1:
+            raise ValueError
+        return n
+    except ValueError:
+        raise argparse.ArgumentTypeError(
+            f"Invalid sample value '{value}'. Use an integer >= 1 (files) or a float in (0, 1) (fraction).")
+
+
+def add_sample_argument(parser) -> None:
+    parser.add_argument("--sample", default=None, type=_parse_sample, metavar="N_OR_FRAC",
+                        help="Process only a random subset: integer >= 1 = that many files, float in (0,1) = "
+                             "that fraction. Deterministic (seed 42).")
