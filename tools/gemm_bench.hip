@@ -1,0 +1,77 @@
+// Dev tool: time the GEMM kernels on the encoder's real shapes (random data).  Build:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I vtc_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "gemm.cuh"
+#include "gemm256.cuh"
+using namespace vtc;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int M, N, K; int rows_per_batch; long long row_stride, batch_stride; int epi; };
+
+template <int EPI> void run(const Shape& s, GemmParams p, int which, hipStream_t st) {
+  if (which == 128) launch_gemm<true, 128, EPI>(p, 1, st);
+  else launch_gemm256<true, EPI>(p, 1, st);
+}
+
+int main(int argc, char** argv) {
+  int iters = argc > 1 ? atoi(argv[1]) : 10;
+  std::vector<Shape> shapes = {
+      {"conv1  M=1.02M N=512  K=1536 (implicit)", 64 * 15999, 512, 1536, 15999, 1024, 31999LL * 512, EPI_GELU},
+      {"conv2  M=512K  N=512  K=1536 (implicit)", 64 * 7999, 512, 1536, 7999, 1024, 15999LL * 512, EPI_GELU},
+      {"conv5  M=64K   N=512  K=1024 (implicit)", 64 * 999, 512, 1024, 999, 1024, 1999LL * 512, EPI_GELU},
+      {"qkv    M=31936 N=2304 K=768", 31936, 2304, 768, 31936, 768, 0, EPI_BIAS},
+      {"oproj  M=31936 N=768  K=768  (+resid f32)", 31936, 768, 768, 31936, 768, 0, EPI_BIAS | EPI_RESID | EPI_F32},
+      {"ffn1   M=31936 N=3072 K=768  (gelu)", 31936, 3072, 768, 31936, 768, 0, EPI_BIAS | EPI_GELU},
+      {"ffn2   M=31936 N=768  K=3072 (+resid f32)", 31936, 768, 3072, 31936, 3072, 0, EPI_BIAS | EPI_RESID | EPI_F32},
+      {"square M=8192  N=8192 K=8192", 8192, 8192, 8192, 8192, 8192, 0, EPI_BIAS},
+  };
+  size_t maxA = 0, maxW = 0, maxC = 0;
+  for (auto& s : shapes) {
+    size_t a = s.batch_stride ? (size_t)(s.M / s.rows_per_batch) * s.batch_stride + s.K : (size_t)s.M * s.K;
+    maxA = std::max(maxA, a); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N);
+  }
+  h16 *A, *W; float *C, *R, *bias;
+  CK(hipMalloc(&A, maxA * 2 + 4096)); CK(hipMalloc(&W, maxW * 2)); CK(hipMalloc(&C, maxC * 4)); CK(hipMalloc(&R, maxC * 4));
+  CK(hipMalloc(&bias, 8192 * 4));
+  {
+    std::vector<unsigned short> h(std::max(maxA, maxW));
+    srand(1);
+    for (auto& v : h) { _Float16 x = (_Float16)((rand() % 2001 - 1000) / 1000.0f); memcpy(&v, &x, 2); }
+    CK(hipMemcpy(A, h.data(), maxA * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), maxW * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(R, 0, maxC * 4)); CK(hipMemset(bias, 0, 8192 * 4));
+  }
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto& s : shapes) {
+    GemmParams p{};
+    p.A = A; p.W = W; p.C = C; p.bias = bias; p.resid = R; p.M = s.M; p.N = s.N; p.K = s.K; p.ldc = s.N;
+    p.rows_per_batch = s.rows_per_batch; p.a_row_stride = s.row_stride; p.a_batch_stride = s.batch_stride;
+    for (int which : {128, 256}) {
+      auto go = [&]() {
+        switch (s.epi) {
+          case EPI_GELU: run<EPI_GELU>(s, p, which, st); break;
+          case EPI_BIAS: run<EPI_BIAS>(s, p, which, st); break;
+          case EPI_BIAS | EPI_GELU: run<EPI_BIAS | EPI_GELU>(s, p, which, st); break;
+          default: run<EPI_BIAS | EPI_RESID | EPI_F32>(s, p, which, st); break;
+        }
+      };
+      go(); go();
+      CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) go();
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("%-46s tile %3d  %8.3f ms  %7.1f TFLOP/s\n", s.name, which, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+    }
+  }
+  return 0;
+}

@@ -36,6 +36,71 @@ struct GemmParams {
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue through LDS: a wave parks a 64-row x 64-col fp32 piece of its accumulators in a private
+// LDS region (pitch 68 floats), then re-reads it ROW-wise so that bias / GELU / residual / conversion
+// run on 4 or 8 consecutive columns per lane and global accesses are 16 B per lane, branch-free
+// (only the store is predicated).  The 64 local columns map to global columns
+// col_base + (c >> 5) * col_group_stride + (c & 31).
+// ---------------------------------------------------------------------------------------------
+constexpr int kEpiPitch = 68;                       // floats; 272 B rows keep float4 reads 16-B aligned
+constexpr int kEpiWaveBytes = 64 * kEpiPitch * 4;   // 17408
+
+template <bool F16, int EPI>
+__device__ __forceinline__ void epilogue_rows(const float* lds, const GemmParams& p, int row_base, int col_base,
+                                              int col_group_stride, int ccol_z, int lane) {
+  if constexpr (EPI & EPI_F32) {
+    const int c4 = (lane & 15) * 4;
+    const int col = col_base + (c4 >> 5) * col_group_stride + (c4 & 31);
+    const bool col_ok = col < p.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI & EPI_BIAS) bv = *(const float4*)(p.bias + ccol_z + (col_ok ? col : 0));
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 4 + (lane >> 4);
+      const int row = row_base + r;
+      const int row_c = row < p.M ? row : p.M - 1;
+      float4 v = *(const float4*)(lds + r * kEpiPitch + c4);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      if constexpr (EPI & EPI_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+      const long long idx = (long long)row_c * p.ldc + ccol_z + (col_ok ? col : 0);
+      if constexpr (EPI & EPI_RESID) {
+        const float4 rv = *(const float4*)(p.resid + idx);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if (row < p.M && col_ok) *(float4*)((float*)p.C + idx) = v;
+    }
+  } else {
+    const int c8 = (lane & 7) * 8;
+    const int col = col_base + (c8 >> 5) * col_group_stride + (c8 & 31);
+    const bool col_ok = col < p.N;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI & EPI_BIAS) {
+      const float4 b0 = *(const float4*)(p.bias + ccol_z + (col_ok ? col : 0));
+      const float4 b1 = *(const float4*)(p.bias + ccol_z + (col_ok ? col : 0) + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3);
+      const int row = row_base + r;
+      const float4 v0 = *(const float4*)(lds + r * kEpiPitch + c8);
+      const float4 v1 = *(const float4*)(lds + r * kEpiPitch + c8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] += bv[k];
+        if constexpr (EPI & EPI_GELU) v[k] = gelu_f(v[k]);
+      }
+      if (row < p.M && col_ok) {
+        const long long idx = (long long)row * p.ldc + ccol_z + col;
+        *(uint4*)((h16*)p.C + idx) = make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]),
+                                                pack2<F16>(v[6], v[7]));
+      }
+    }
+  }
+}
+
 template <bool F16, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int BM = 128;
@@ -43,7 +108,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int NJ = WN / 16;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int W_INSTR = BN / 32;  // glds instructions per wave for the W tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  constexpr int SMEM_BYTES = 2 * STAGE_BYTES > 4 * kEpiWaveBytes ? 2 * STAGE_BYTES : 4 * kEpiWaveBytes;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -138,30 +204,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
 
-  // ---- epilogue: C/D map col = lane&15, row = (lane>>4)*4 + reg
-  const int col0 = tile_n * BN + wn * WN + fr;
-  const int row0 = tile_m * BM + wm * 64 + fq * 4;
-  const int ccol_z = z * p.c_col_z;
+  // ---- epilogue through LDS (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
+  __syncthreads();  // every wave is done reading the last K-tile
+  float* my = (float*)(smem + wave * kEpiWaveBytes);
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int col = col0 + j * 16;
-    if (col >= p.N) continue;
-    float bv = 0.f;
-    if constexpr (EPI & EPI_BIAS) bv = p.bias[ccol_z + col];
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + i * 16 + r;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if constexpr (EPI & EPI_GELU) v = gelu_f(v);
-        const long long idx = (long long)row * p.ldc + ccol_z + col;
-        if constexpr (EPI & EPI_RESID) v += p.resid[idx];
-        if constexpr (EPI & EPI_F32) ((float*)p.C)[idx] = v;
-        else ((h16*)p.C)[idx] = to_h16<F16>(v);
-      }
-    }
+      for (int r = 0; r < 4; ++r) my[(i * 16 + fq * 4 + r) * kEpiPitch + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+  if constexpr (NJ == 4) {
+    epilogue_rows<F16, EPI>(my, p, tile_m * BM + wm * 64, tile_n * BN + wn * WN, 32, z * p.c_col_z, lane);
+  } else {
+    // 32 live columns per wave: lanes whose column falls in the dead half are masked by col < N or by pairing
+    GemmParams q = p;
+    q.N = min(p.N, tile_n * BN + wn * WN + WN);
+    epilogue_rows<F16, EPI>(my, q, tile_m * BM + wm * 64, tile_n * BN + wn * WN, 32, z * p.c_col_z, lane);
   }
 }
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,6 +16,7 @@
 #include "decode_kernels.cuh"
 #include "encoder_kernels.cuh"
 #include "gemm.cuh"
+#include "gemm256.cuh"
 
 using namespace vtc;
 
@@ -76,6 +78,7 @@ struct vtc_model {
   float* dec_max = nullptr;
 
   int debug_stop = -1;
+  bool big_tiles = true;   // 256x256 8-phase GEMM (VTC_GEMM_TILE=128 selects the 128x128 kernel, for A/B runs)
 
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -192,7 +195,14 @@ void prof_end(vtc_model* m, hipStream_t s) {
 template <bool F16, int BN, int EPI>
 void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
-  LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
+  // 256x256 tiles pay off once there are >= 4 full rounds of them over the 256 CUs (measured with
+  // tools/gemm_bench: conv layers 1-4 yes, the K=768 / M=31936 transformer GEMMs no: tile quantisation).
+  const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * nz;
+  if (BN == 128 && m->big_tiles && p.N % 256 == 0 && p.K % 128 == 0 && tiles256 >= 1024) {
+    LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI>(p, nz, s)));
+  } else {
+    LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
+  }
 }
 
 GemmParams plain(const h16* A, const h16* W, void* C, const float* bias, const float* resid, int M, int N, int K) {
@@ -362,6 +372,7 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   m->spec = *spec;
   m->device = device;
   m->f16 = spec->mfma_dtype == 1;
+  if (const char* e = getenv("VTC_GEMM_TILE")) m->big_tiles = atoi(e) != 128;
   m->T = (int)T;
   {
     int n = spec->window_samples;

@@ -89,6 +89,9 @@ def load() -> C.CDLL:
     """Load the HIP library once; raise if it is missing (never fall back to a CPU path)."""
     global _lib
     if _lib is None:
+        # torch first: PyTorch-ROCm ships its own libamdhip64; libvtc_amd.so must bind to that one so that
+        # the process holds a single HIP/HSA runtime (two runtimes in one process see no devices).
+        import torch  # noqa: F401
         if not LIB_PATH.exists():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C vtc_amd/csrc` (or __graft_entry__.build()); "
