@@ -16,7 +16,13 @@ struct Shape { const char* name; int M, N, K; int rows_per_batch; long long row_
 
 template <int EPI> void run(const Shape& s, GemmParams p, int which, hipStream_t st) {
   if (which == 128) launch_gemm<true, 128, EPI>(p, 1, st);
-  else launch_gemm256<true, EPI>(p, 1, st);
+  else if (which == 256) { if (p.N % 256 == 0) launch_gemm256<true, EPI, 256>(p, 1, st); }
+  else if (which == 192) { if (p.N % 192 == 0) launch_gemm256<true, EPI, 192>(p, 1, st); }
+  else if (which == 1281) launch_gemm<true, 128, EPI, 1>(p, 1, st);
+  else if (which == 1282) launch_gemm<true, 128, EPI, 2>(p, 1, st);
+  else if (which == 1283) launch_gemm<true, 128, EPI, 3>(p, 1, st);
+  else if (which == 1284) launch_gemm<true, 128, EPI, 4>(p, 1, st);
+  else if (which == 1286) launch_gemm<true, 128, EPI, 6>(p, 1, st);
 }
 
 int main(int argc, char** argv) {
@@ -53,7 +59,7 @@ int main(int argc, char** argv) {
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.bias = bias; p.resid = R; p.M = s.M; p.N = s.N; p.K = s.K; p.ldc = s.N;
     p.rows_per_batch = s.rows_per_batch; p.a_row_stride = s.row_stride; p.a_batch_stride = s.batch_stride;
-    for (int which : {128, 256}) {
+    for (int which : {128, 256, 192}) {
       auto go = [&]() {
         switch (s.epi) {
           case EPI_GELU: run<EPI_GELU>(s, p, which, st); break;
@@ -70,7 +76,7 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       ms /= iters;
-      printf("%-46s tile %3d  %8.3f ms  %7.1f TFLOP/s\n", s.name, which, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+      printf("%-46s tile %4d  %8.3f ms  %7.1f TFLOP/s\n", s.name, which, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
     }
   }
   return 0;

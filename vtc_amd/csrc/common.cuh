@@ -50,7 +50,7 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma32(u16x8 a, u16x8 b, f
 // (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7); the erfc form keeps the negative tail relative-accurate.
 __device__ __forceinline__ float gelu_f(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));  // v_rcp_f32 (1 ulp); a true divide costs 11 VALU
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -101,7 +101,9 @@ __device__ __forceinline__ void epilogue_rows(const float* lds, const GemmParams
   }
 }
 
-template <bool F16, int BN, int EPI>
+// ABL (dev-only ablations, tools/gemm_bench.hip): 1 = no global loads after the first tile, 2 = ds_read only
+// on the first K-tile, 4 = no MFMA.  ABL = 0 in the library.
+template <bool F16, int BN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int BM = 128;
   constexpr int WN = BN / 2;
@@ -182,25 +184,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 
   const int nk = p.K >> 6;
+  u16x8 af[2][4], bf[2][NJ];
   stage(0, 0);
   for (int kb = 0; kb < nk; ++kb) {
     const int cur = kb & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kb + 1 < nk) stage(cur ^ 1, kb + 1);
+    if (kb + 1 < nk && !((ABL & 1) && kb > 0)) stage(cur ^ 1, kb + 1);
     const char* base = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u16x8 af[4], bf[NJ];
       const int c = ks * 4 + fq;
+      if (!((ABL & 2) && kb > 0)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const u16x8*)(base + a_off[i] + ((c ^ a_sw[i]) << 4));
+        for (int i = 0; i < 4; ++i) af[ks][i] = *(const u16x8*)(base + a_off[i] + ((c ^ a_sw[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = *(const u16x8*)(base + b_off[j] + ((c ^ b_sw[j]) << 4));
+        for (int j = 0; j < NJ; ++j) bf[ks][j] = *(const u16x8*)(base + b_off[j] + ((c ^ b_sw[j]) << 4));
+      }
+      if constexpr (ABL & 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[ks][i]));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[ks][j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<F16>(af[ks][i], bf[ks][j], acc[i][j]);
+      }
     }
   }
 
@@ -224,12 +235,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <bool F16, int BN, int EPI>
+template <bool F16, int BN, int EPI, int ABL = 0>
 inline void launch_gemm(GemmParams p, int nz, hipStream_t s) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nz);
-  hipLaunchKernelGGL((gemm_kernel<F16, BN, EPI>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<F16, BN, EPI, ABL>), grid, dim3(256), 0, s, p);
 }
 
 }  // namespace vtc

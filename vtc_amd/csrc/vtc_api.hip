@@ -195,14 +195,13 @@ void prof_end(vtc_model* m, hipStream_t s) {
 template <bool F16, int BN, int EPI>
 void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
-  // 256x256 tiles pay off once there are >= 4 full rounds of them over the 256 CUs (measured with
-  // tools/gemm_bench: conv layers 1-4 yes, the K=768 / M=31936 transformer GEMMs no: tile quantisation).
-  const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * nz;
-  if (BN == 128 && m->big_tiles && p.N % 256 == 0 && p.K % 128 == 0 && tiles256 >= 1024) {
-    LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI>(p, nz, s)));
-  } else {
-    LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
+  // Tile choice (measured with tools/gemm_bench): the persistent 256 x BN kernel needs N % BN == 0 and
+  // K % 128 == 0; BN = 256 where N allows (conv 512, QKV 2304, FFN1 3072), BN = 192 for N = 768.
+  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.M >= 4096) {
+    if (p.N % 256 == 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
+    if (p.N % 192 == 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
   }
+  LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
 }
 
 GemmParams plain(const h16* A, const h16* W, void* C, const float* bias, const float* resid, int M, int N, int K) {
