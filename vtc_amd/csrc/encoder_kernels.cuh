@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over rows; one wave per row, two-pass (mean, then centred variance) in registers.
 //   D = 512: 16-bit input (conv6 output), 16-bit output.
-//   D = 768: fp32 input, fp32 + 16-bit outputs; HEAD fuses the per-frame multi-label head
+//   D = 768: fp32 input, 16-bit output (the residual stream is kept 16-bit; fp32 copy only if out32 != null); HEAD fuses the per-frame multi-label head
 //            (n_labels linear units on the normalised row, fp32) and writes stitched logits.
 // ---------------------------------------------------------------------------------------------
 struct HeadParams {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restri
     v[4 * i + 1] = fmaf(v[4 * i + 1] * rstd, gg.y, bb.y);
     v[4 * i + 2] = fmaf(v[4 * i + 2] * rstd, gg.z, bb.z);
     v[4 * i + 3] = fmaf(v[4 * i + 3] * rstd, gg.w, bb.w);
-    *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    if (out32) *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
     *(uint2*)(out16 + (long long)row * 768 + c) =
         make_uint2(pack2<F16>(v[4 * i], v[4 * i + 1]), pack2<F16>(v[4 * i + 2], v[4 * i + 3]));
   }

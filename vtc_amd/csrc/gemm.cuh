@@ -15,7 +15,7 @@
 
 namespace vtc {
 
-enum : int { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_F32 = 8 };
+enum : int { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_F32 = 8, EPI_RESID16 = 16 };  // RESID16: residual stored 16-bit
 
 struct GemmParams {
   const h16* A;
@@ -67,6 +67,10 @@ __device__ __forceinline__ void epilogue_rows(const float* lds, const GemmParams
       if constexpr (EPI & EPI_RESID) {
         const float4 rv = *(const float4*)(p.resid + idx);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if constexpr (EPI & EPI_RESID16) {
+        const u16x4 rv = *(const u16x4*)((const h16*)p.resid + idx);
+        v.x += from_h16<F16>(rv[0]); v.y += from_h16<F16>(rv[1]); v.z += from_h16<F16>(rv[2]); v.w += from_h16<F16>(rv[3]);
       }
       if (row < p.M && col_ok) *(float4*)((float*)p.C + idx) = v;
     }

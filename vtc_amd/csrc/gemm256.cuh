@@ -315,6 +315,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
               const float4 rv = *(const float4*)(p.resid + idx);
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
+            if constexpr (EPI & EPI_RESID16) {
+              const u16x4 rv = *(const u16x4*)((const h16*)p.resid + idx);
+              v.x += from_h16<F16>(rv[0]); v.y += from_h16<F16>(rv[1]);
+              v.z += from_h16<F16>(rv[2]); v.w += from_h16<F16>(rv[3]);
+            }
             if (row < p.M && col_ok) *(float4*)((float*)p.C + idx) = v;
           }
         } else {

@@ -59,7 +59,7 @@ struct vtc_model {
 
   // workspace
   h16 *actA = nullptr, *actB = nullptr, *x16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffn16 = nullptr, *posin = nullptr;
-  float *h0 = nullptr, *tmp32 = nullptr, *x32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+  float *h0 = nullptr, *tmp32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
   double* mom_partial = nullptr;
   int nchunk = 0;
 
@@ -198,8 +198,12 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   // Tile choice (measured with tools/gemm_bench): the persistent 256 x BN kernel needs N % BN == 0 and
   // K % 128 == 0; BN = 256 where N allows (conv 512, QKV 2304, FFN1 3072), BN = 192 for N = 768.
   if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.M >= 4096) {
-    if (p.N % 256 == 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
-    if (p.N % 192 == 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
+    // rounds of tiles over the 256 CUs x tile width ~ time; BN = 192 only when clearly fewer (N = 768: 2 x 192 vs 2 x 256)
+    const long long tm = (p.M + 255) / 256;
+    const long long c256 = p.N % 256 == 0 ? ((tm * (p.N / 256) * nz + 255) / 256) * 256 : -1;
+    const long long c192 = p.N % 192 == 0 ? ((tm * (p.N / 192) * nz + 255) / 256) * 192 : -1;
+    if (c256 > 0 && (c192 < 0 || 10 * c192 >= 8 * c256)) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
+    if (c192 > 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
   }
   LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
 }
@@ -264,7 +268,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   HeadParams nohead{};
   LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
          hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, m->enc_ln_w,
-                            m->enc_ln_b, m->x32, m->x16, M, nohead));
+                            m->enc_ln_b, (float*)nullptr, m->x16, M, nohead));
   if (m->debug_stop == 8) return 0;
 
   // ---- 12 post-LN transformer layers
@@ -277,23 +281,23 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
     LAUNCH(m, PC_ATTN, attn_flops, 0.0, s,
            hipLaunchKernelGGL((attention_kernel<F16>), dim3((nkt + kAttnWaves - 1) / kAttnWaves, nw * 12), dim3(512),
                               attn_lds, s, m->qkv16, m->ctx16, T, nkt));
-    gemm_go<F16, 128, EPI_BIAS | EPI_RESID | EPI_F32>(m, plain(m->ctx16, w.o_w, m->tmp32, w.o_b, m->x32, M, 768, 768), 1, s);
+    gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(m->ctx16, w.o_w, m->tmp32, w.o_b, (const float*)m->x16, M, 768, 768), 1, s);
     LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
            hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln1_w,
-                              w.ln1_b, m->x32, m->x16, M, nohead));
+                              w.ln1_b, (float*)nullptr, m->x16, M, nohead));
     gemm_go<F16, 128, EPI_BIAS | EPI_GELU>(m, plain(m->x16, w.ff1_w, m->ffn16, w.ff1_b, nullptr, M, 3072, 768), 1, s);
-    gemm_go<F16, 128, EPI_BIAS | EPI_RESID | EPI_F32>(m, plain(m->ffn16, w.ff2_w, m->tmp32, w.ff2_b, m->x32, M, 768, 3072), 1, s);
+    gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(m->ffn16, w.ff2_w, m->tmp32, w.ff2_b, (const float*)m->x16, M, 768, 3072), 1, s);
     const bool last = l == VTC_N_LAYERS - 1;
     if (!last || m->debug_stop == 9 + l) {
       LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
              hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
-                                w.ln2_b, m->x32, m->x16, M, nohead));
+                                w.ln2_b, (float*)nullptr, m->x16, M, nohead));
     } else {
       // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
       HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
       LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
              hipLaunchKernelGGL((layernorm768_kernel<F16, true>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
-                                w.ln2_b, m->x32, m->x16, M, hp));
+                                w.ln2_b, (float*)nullptr, m->x16, M, hp));
     }
     if (m->debug_stop == 9 + l) return 0;
   }
@@ -433,7 +437,6 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   TRY(dev_alloc(m, &m->actB, std::max(B * (size_t)m->L[1] * 512, MT * 512)));
   TRY(dev_alloc(m, &m->h0, MT * 768));
   TRY(dev_alloc(m, &m->tmp32, MT * 768));
-  TRY(dev_alloc(m, &m->x32, MT * 768));
   TRY(dev_alloc(m, &m->x16, MT * 768));
   TRY(dev_alloc(m, &m->qkv16, MT * 2304));
   TRY(dev_alloc(m, &m->ctx16, MT * 768));
@@ -592,7 +595,7 @@ int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t nw, float* out, int
   bool is16 = true;
   if (stage >= 0 && stage <= 6) { src = (stage % 2 == 0) ? m->actA : m->actB; n = (long long)nw * m->L[stage] * 512; }
   else if (stage == 7) { src = m->h0; n = (long long)nw * m->T * 768; is16 = false; }
-  else if (stage >= 8 && stage < 9 + VTC_N_LAYERS) { src = m->x32; n = (long long)nw * m->T * 768; is16 = false; }
+  else if (stage >= 8 && stage < 9 + VTC_N_LAYERS) { src = m->x16; n = (long long)nw * m->T * 768; }
   else return fail(m, VTC_ERR_ARG, "unknown stage %d", stage);
   if (n > cap) return fail(m, VTC_ERR_CAPACITY, "stage %d needs %lld floats", stage, n);
   if (!is16) {
