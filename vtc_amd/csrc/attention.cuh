@@ -1,44 +1,47 @@
-// Multi-head self-attention for one window (T <= 512 frames, 12 heads x 64), flash-style.
+// Multi-head self-attention for one window (12 heads x 64), flash-style, K/V streamed through LDS.
 // Arithmetic: softmax(q k^T) v with q pre-scaled by 64^-0.5 (HF modeling_hubert.py:234-260, 318-341).
 //
 // Layout choices (v_mfma_f32_32x32x16, C/D: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)):
-//   * S^T = K * Q^T, so the QUERY sits on the lane and a query's keys sit in the 16 accumulator
-//     registers (+ the other half-wave): row max / row sum need no LDS and one cross-half shuffle.
+//   * S^T = K * Q^T, so the QUERY sits on the lane and a query's keys sit in the accumulator registers
+//     (+ the other half-wave): row max / row sum need no LDS and one cross-half shuffle.
 //   * O^T = V^T * P^T: the S^T accumulators, converted to 16 bit, ARE the B operand (no lane movement);
 //     the matching V^T fragments come from the row-major V image by ds_read_b64_tr_b16.
-// The whole K and V of one (window, head) live in LDS (2 x nkt*32 x 128 B <= 128 KiB).
+//   * a block = 8 waves x 32 queries of one (window, head); K and V arrive in 64-key tiles by
+//     global_load_lds into a 2-stage ring (32 KiB), so several blocks share a CU and hide each other's
+//     waits.  K rows are XOR-swizzled for the ds_read_b128 fragment reads, V rows for the transposed reads.
+//   * online softmax over 64 keys per step; the running-max rescale of O is skipped when no query of the
+//     wave raised its maximum (exact, wave-uniform branch).
 #pragma once
 #include "common.cuh"
 
 namespace vtc {
 
 constexpr int kAttnWaves = 8;
+constexpr int kAttnStage = 16384;  // K tile 64 x 128 B, then V tile 64 x 128 B
 
 template <bool F16>
-__global__ __launch_bounds__(512) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx, int T, int nkt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + nkt * 32 * 128;
+__global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx, int T, int nkt) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kAttnStage];
   const int b = blockIdx.y / 12, h = blockIdx.y - b * 12;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long rowbase = (long long)b * T;
 
-  for (int idx = tid; idx < nkt * 32 * 8; idx += 512) {
-    const int key = idx >> 3, c = idx & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
-    if (key < T) {
-      const h16* src = qkv + (rowbase + key) * 2304 + h * 64 + c * 8;
-      kv = *(const uint4*)(src + 768);
-      vv = *(const uint4*)(src + 1536);
-    }
-    *(uint4*)(Ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
-    *(uint4*)(Vs + key * 128 + (c << 4)) = vv;
-  }
-  __syncthreads();
+  // ---- staging: one 16-B piece of K and one of V per thread per 64-key tile
+  const int srow = wave * 8 + (lane >> 3), sc = lane & 7;
+  const int k_chunk = sc ^ ((srow >> 1) & 7);
+  const int v_chunk = sc ^ (((srow >> 1) & 1) << 2);
+  auto stage = [&](int buf, int kt) {
+    int key = kt * 64 + srow;
+    key = key < T ? key : T - 1;   // clamped rows are masked (K) or multiplied by P = 0 (V)
+    const h16* src = qkv + (rowbase + key) * 2304 + h * 64;
+    char* dst = smem + buf * kAttnStage + wave * 1024;
+    __builtin_amdgcn_global_load_lds(GPTR(src + 768 + k_chunk * 8), LPTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GPTR(src + 1536 + v_chunk * 8), LPTR(dst + 8192), 16, 0, 0);
+  };
 
   const int q0 = (blockIdx.x * kAttnWaves + wave) * 32;
-  if (q0 >= T) return;  // whole wave leaves together (wave-uniform), after the only barrier
+  const bool active = q0 < T;   // wave-uniform; idle waves still stage and hit the barriers
   const int r = lane & 31, hh = lane >> 5;
 
   u16x8 qf[4];
@@ -54,62 +57,87 @@ __global__ __launch_bounds__(512) void attention_kernel(const h16* __restrict__ 
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
   float m = -1e30f, l = 0.f;
 
-  // V^T fragment address (bytes) of this lane inside a key tile: 4-key x 16-col block per 16-lane group
-  const int v_lane_off = (4 * hh + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  // K fragment: row = u*32 + r, 16-B chunk (2*st + hh) ^ swz(row);  swz(row) = (row>>1)&7 is the same for u = 0,1
+  const int k_row_off = r * 128;
+  const int k_sw = (r >> 1) & 7;
+  // V^T fragment (4-key x 16-col block per 16-lane group): key row = 16*st2 + 4*hh + q (+8), col bytes 32*g1 + 8*p
+  const int vq = (lane & 15) >> 2;
+  const int v_row_off = (4 * hh + vq) * 128;
+  const int v_col = (32 * ((lane >> 4) & 1) + 8 * (lane & 3)) ^ (((vq >> 1) & 1) << 6);   // dt = 0; dt = 1 is ^ 64
 
+  stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    f32x16 s;
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    if (!active) continue;
+    const char* Ks = smem + cur * kAttnStage;
+    const char* Vs = Ks + 8192;
+
+    f32x16 s0, s1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = 0.f;
-    const int krow = kt * 32 + r;
-    const char* kbase = Ks + krow * 128;
-    const int ksw = (krow >> 1) & 7;
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const u16x8 kf = *(const u16x8*)(kbase + (((2 * st + hh) ^ ksw) << 4));
-      s = mfma32<F16>(kf, qf[st], s);
+      const int co = ((2 * st + hh) ^ k_sw) << 4;
+      const u16x8 k0 = *(const u16x8*)(Ks + k_row_off + co);
+      const u16x8 k1 = *(const u16x8*)(Ks + 32 * 128 + k_row_off + co);
+      s0 = mfma32<F16>(k0, qf[st], s0);
+      s1 = mfma32<F16>(k1, qf[st], s1);
     }
     if (kt == nkt - 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (key >= T) s[i] = -1e30f;
+        const int key = kt * 64 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= T) s0[i] = -1e30f;
+        if (key + 32 >= T) s1[i] = -1e30f;
       }
     }
-    float mx = s[0];
+    float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __expf(m - m_new);
-    m = m_new;
+    if (__any(mx > m)) {   // some query of this wave raised its running maximum: rescale (exact)
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __expf(m - m_new);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    }
     float psum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - m); psum += s[i]; }
-    l = fmaf(l, alpha, psum);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = __expf(s0[i] - m);
+      s1[i] = __expf(s1[i] - m);
+      psum += s0[i] + s1[i];
+    }
+    l += psum;
 
-    const char* vt = Vs + kt * 32 * 128 + v_lane_off;
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      u16x8 pf;
+    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = to_h16<F16>(s[8 * st + j]);
-      const char* va = vt + st * 16 * 128;
+      for (int st = 0; st < 2; ++st) {
+        u16x8 pf;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + dt * 64));
-        const s16x4 v2 =
-            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + dt * 64 + 8 * 128));
-        u16x8 vf;
+        for (int j = 0; j < 8; ++j) pf[j] = to_h16<F16>(u ? s1[8 * st + j] : s0[8 * st + j]);
+        const char* va = Vs + (u * 32 + st * 16) * 128 + v_row_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vf[j] = (unsigned short)v1[j]; vf[4 + j] = (unsigned short)v2[j]; }
-        if (dt == 0) o0 = mfma32<F16>(vf, pf, o0);
-        else         o1 = mfma32<F16>(vf, pf, o1);
+        for (int dt = 0; dt < 2; ++dt) {
+          const int vc = v_col ^ (dt << 6);
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + vc));
+          const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * 128 + vc));
+          u16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = (unsigned short)v1[j]; vf[4 + j] = (unsigned short)v2[j]; }
+          if (dt == 0) o0 = mfma32<F16>(vf, pf, o0);
+          else         o1 = mfma32<F16>(vf, pf, o1);
+        }
       }
     }
   }
+  if (!active) return;
 
   l += __shfl_xor(l, 32);
   const float inv = 1.f / l;

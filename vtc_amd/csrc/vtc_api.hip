@@ -272,15 +272,14 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   if (m->debug_stop == 8) return 0;
 
   // ---- 12 post-LN transformer layers
-  const int nkt = (T + 31) / 32;
-  const size_t attn_lds = (size_t)nkt * 32 * 128 * 2;
+  const int nkt = (T + 63) / 64;                       // 64-key tiles streamed through LDS
+  const int nqb = ((T + 31) / 32 + kAttnWaves - 1) / kAttnWaves;   // blocks of 8 x 32 queries
   const double attn_flops = 4.0 * (double)nw * 12 * (double)T * T * 64;
   for (int l = 0; l < VTC_N_LAYERS; ++l) {
     const LayerDev& w = m->layer[l];
     gemm_go<F16, 128, EPI_BIAS>(m, plain(m->x16, w.qkv_w, m->qkv16, w.qkv_b, nullptr, M, 2304, 768), 1, s);
     LAUNCH(m, PC_ATTN, attn_flops, 0.0, s,
-           hipLaunchKernelGGL((attention_kernel<F16>), dim3((nkt + kAttnWaves - 1) / kAttnWaves, nw * 12), dim3(512),
-                              attn_lds, s, m->qkv16, m->ctx16, T, nkt));
+           hipLaunchKernelGGL((attention_kernel<F16>), dim3(nqb, nw * 12), dim3(512), 0, s, m->qkv16, m->ctx16, T, nkt));
     gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(m->ctx16, w.o_w, m->tmp32, w.o_b, (const float*)m->x16, M, 768, 768), 1, s);
     LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
            hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln1_w,
@@ -360,7 +359,7 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   if (spec->mfma_dtype != 0 && spec->mfma_dtype != 1) return fail(nullptr, VTC_ERR_ARG, "mfma_dtype must be 0 (bf16) or 1 (f16)");
   const long long T = vtc_frames_for_samples(spec->window_samples);
   if (T < 1 || T > 512)
-    return fail(nullptr, VTC_ERR_ARG, "window of %d samples gives %lld frames; supported 1..512 (K/V of a head must fit LDS)",
+    return fail(nullptr, VTC_ERR_ARG, "window of %d samples gives %lld frames; supported 1..512",
                 spec->window_samples, T);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VTC_ERR_NO_GPU, "no HIP device visible");
@@ -455,11 +454,6 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   for (auto& e : m->slot_ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipEventCreate failed"));
 
-  // attention needs up to 128 KiB of dynamic LDS
-  const int lds = ((m->T + 31) / 32) * 32 * 128 * 2;
-  hipError_t e = f16 ? hipFuncSetAttribute((const void*)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                     : hipFuncSetAttribute((const void*)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipFuncSetAttribute(attention LDS %d) -> %s", lds, hipGetErrorString(e)));
 #undef TRY
   *out = m;
   return VTC_OK;
