@@ -17,6 +17,7 @@
 #include "encoder_kernels.cuh"
 #include "gemm.cuh"
 #include "gemm256.cuh"
+#include "posconv.cuh"
 
 using namespace vtc;
 
@@ -257,14 +258,9 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   // ---- positional conv (16 groups x [T x 6144] x [6144 x 48]) + GELU + residual, then LayerNorm
   LAUNCH(m, PC_PACK, 0.0, (double)M * 768 * 6, s,
          hipLaunchKernelGGL((posconv_pack_kernel<F16>), dim3(T + 128, nw), dim3(256), 0, s, m->h0, m->posin, T));
-  {
-    GemmParams p{};
-    p.A = m->posin; p.W = m->pos_w; p.C = m->tmp32; p.bias = m->pos_b; p.resid = m->h0;
-    p.M = M; p.N = 48; p.K = 6144; p.ldc = 768;
-    p.rows_per_batch = T; p.a_row_stride = 48; p.a_batch_stride = (long long)16 * (T + 128) * 48;
-    p.a_z_stride = (long long)(T + 128) * 48; p.w_z_stride = (long long)64 * 6144; p.c_col_z = 48;
-    gemm_go<F16, 64, EPI_BIAS | EPI_GELU | EPI_RESID | EPI_F32>(m, p, 16, s);
-  }
+  LAUNCH(m, PC_GEMM, 2.0 * M * 768.0 * 48 * 128, 0.0, s,
+         hipLaunchKernelGGL((posconv_kernel<F16>), dim3((T + kPcRows - 1) / kPcRows, 16, nw), dim3(256), 0, s, m->posin,
+                            m->pos_w, m->pos_b, m->h0, m->tmp32, T));
   HeadParams nohead{};
   LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
          hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, m->enc_ln_w,
