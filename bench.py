@@ -49,6 +49,20 @@ def conv_lengths(w: int) -> list[int]:
     return out
 
 
+def measured_traffic(kernel_substr: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json), launch-weighted
+    over the kernels whose name contains kernel_substr; None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    ks = [k for k in json.load(open(files[-1]))["kernels"] if kernel_substr in k["kernel"]]
+    n = sum(k["launches_profiled"] for k in ks)
+    if not n:
+        return None
+    return sum((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * k["launches_profiled"] for k in ks) / n
+
+
 def cpu_baseline(chunk_s: float, n_windows: int, batch: int) -> dict:
     """The fp32 CPU oracle (oracle/vtc_oracle.py) timed on this host's cores on a bounded sample."""
     from oracle import vtc_oracle as O
@@ -157,9 +171,9 @@ def main() -> None:
         if prof is not None:
             g = prof["gemm_mfma"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (all dense contractions: conv1-6 implicit GEMM, "
-                               "projection, pos-conv, QKV, out-proj, FFN)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel / gemm_kernel / posconv_kernel (all dense contractions: conv1-6 "
+                               "implicit GEMM, projection, pos-conv, QKV, out-proj, FFN)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": measured_traffic("gemm"),
                                "launches_per_step": g["launches"] / args.steps,
                                "avg_launch_ms": g["ms"] / max(g["launches"], 1)}
             c = prof["conv0_apply"]
@@ -167,7 +181,7 @@ def main() -> None:
                 gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9
                 out["roofline_hbm"] = {"bound": "hbm", "kernel": "conv0_apply_kernel (conv0 + GroupNorm + GELU)",
                                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                       "traffic": None, "avg_launch_ms": c["ms"] / max(c["launches"], 1)}
+                                       "traffic": measured_traffic("conv0_apply"), "avg_launch_ms": c["ms"] / max(c["launches"], 1)}
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.chunk, args.cpu_windows, 8)
