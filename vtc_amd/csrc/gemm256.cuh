@@ -265,10 +265,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.  LDS image [16][64] fp32, the
     // 16-B chunk index XORed with (row>>2)<<2 so that the four row groups of a write hit different banks.
     const int ccol_z = z * p.c_col_z;
+    // Global accesses go through buffer descriptors: lanes outside the matrix get the offset 0x80000000 and the
+    // hardware drops the access (loads return 0), so the epilogue has no branches and vmcnt stays countable.
+    constexpr int ESZ = (EPI & EPI_F32) ? 4 : 2;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)((long long)p.M * p.ldc * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.resid, 0, (EPI & (EPI_RESID | EPI_RESID16)) ? (int)((long long)p.M * p.ldc * ((EPI & EPI_RESID16) ? 2 : 4)) : 0,
+        0x00020000);
     // per-lane output columns and bias (fp32 out: 4 columns per lane; 16-bit out: 8 columns per lane)
     constexpr int CPL = (EPI & EPI_F32) ? 4 : 8;
-    const int ch = lane & 15, ch8 = lane & 7;
-    const int c0 = ((EPI & EPI_F32) ? ch : ch8) * CPL;
+    constexpr int NIT = (EPI & EPI_F32) ? 4 : 2;          // row iterations per 16-row pass
+    constexpr int RPI = 16 / NIT;                         // rows per iteration
+    const int lrow = (EPI & EPI_F32) ? (lane >> 4) : (lane >> 3);
+    const int lch = (EPI & EPI_F32) ? (lane & 15) : (lane & 7);
+    const int c0 = lch * CPL;
     const int col = tile_n * BN + (c0 < 32 ? wn * 32 + c0 : 128 + wn * (16 * NJ1) + (c0 - 32));
     const bool col_ok = c0 < 32 + 16 * NJ1;
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -280,70 +292,90 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
       }
     }
+    auto elem_index = [&](int pass, int it) -> unsigned {   // element index of this lane's first column, or OOB
+      const int row = tile_m * 256 + (pass >> 2) * 128 + wm * 64 + (pass & 3) * 16 + it * RPI + lrow;
+      return (row < p.M && col_ok) ? (unsigned)(row * p.ldc + ccol_z + col) : OOB;
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // residual of the NEXT pass is fetched before this pass's stores are issued (one pass of prefetch)
+    u32x2 res16[2][4];
+    u32x4 res32[2][4];
+    auto fetch_resid = [&](int pass, int slot) {
+      if constexpr (EPI & EPI_RESID16) {
 #pragma unroll
-    for (int mq = 0; mq < 2; ++mq)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = fq * 4 + r;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int c = j * 16 + fr;
-            epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc0[mq][i][j][r];
-          }
-#pragma unroll
-          for (int j = 0; j < NJ1; ++j) {
-            const int c = 32 + j * 16 + fr;
-            epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc1[mq][i][j][r];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int row_base = tile_m * 256 + mq * 128 + wm * 64 + i * 16;
-        if constexpr (EPI & EPI_F32) {
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int r = it * 4 + (lane >> 4);
-            const int row = row_base + r;
-            const int row_c = row < p.M ? row : p.M - 1;
-            float4 v = *(const float4*)(epi + r * 64 + ((ch ^ ((r >> 2) << 2)) << 2));
-            v.x += bv[0]; v.y += bv[1]; v.z += bv[2]; v.w += bv[3];
-            if constexpr (EPI & EPI_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
-            const long long idx = (long long)row_c * p.ldc + ccol_z + (col_ok ? col : 0);
-            if constexpr (EPI & EPI_RESID) {
-              const float4 rv = *(const float4*)(p.resid + idx);
-              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            if constexpr (EPI & EPI_RESID16) {
-              const u16x4 rv = *(const u16x4*)((const h16*)p.resid + idx);
-              v.x += from_h16<F16>(rv[0]); v.y += from_h16<F16>(rv[1]);
-              v.z += from_h16<F16>(rv[2]); v.w += from_h16<F16>(rv[3]);
-            }
-            if (row < p.M && col_ok) *(float4*)((float*)p.C + idx) = v;
-          }
-        } else {
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int r = it * 8 + (lane >> 3);
-            const int row = row_base + r;
-            const int sw = (r >> 2) << 2;
-            const float4 v0 = *(const float4*)(epi + r * 64 + (((2 * ch8) ^ sw) << 2));
-            const float4 v1 = *(const float4*)(epi + r * 64 + (((2 * ch8 + 1) ^ sw) << 2));
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              v[k] += bv[k];
-              if constexpr (EPI & EPI_GELU) v[k] = gelu_f(v[k]);
-            }
-            if (row < p.M && col_ok) {
-              const long long idx = (long long)row * p.ldc + ccol_z + col;
-              *(uint4*)((h16*)p.C + idx) = make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]),
-                                                      pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7]));
-            }
-          }
+        for (int it = 0; it < NIT; ++it) {
+          const unsigned e = elem_index(pass, it);
+          res16[slot][it] = __builtin_amdgcn_raw_buffer_load_b64(rr, e == OOB ? OOB : e * 2u, 0, 0);
         }
       }
+      if constexpr (EPI & EPI_RESID) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const unsigned e = elem_index(pass, it);
+          res32[slot][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, e == OOB ? OOB : e * 4u, 0, 0);
+        }
+      }
+    };
+    fetch_resid(0, 0);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int mq = pass >> 2, i = pass & 3, slot = pass & 1;
+      if (pass + 1 < 8) fetch_resid(pass + 1, slot ^ 1);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = fq * 4 + r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = j * 16 + fr;
+          epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc0[mq][i][j][r];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) {
+          const int c = 32 + j * 16 + fr;
+          epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc1[mq][i][j][r];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + lrow;
+        const int sw = (r >> 2) << 2;
+        const unsigned e = elem_index(pass, it);
+        float v[8];
+        if constexpr (EPI & EPI_F32) {
+          const float4 x = *(const float4*)(epi + r * 64 + ((lch ^ sw) << 2));
+          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+          const float4 x0 = *(const float4*)(epi + r * 64 + (((2 * lch) ^ sw) << 2));
+          const float4 x1 = *(const float4*)(epi + r * 64 + (((2 * lch + 1) ^ sw) << 2));
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          v[k] += bv[k];
+          if constexpr (EPI & EPI_GELU) v[k] = gelu_f(v[k]);
+        }
+        if constexpr (EPI & EPI_F32) {
+          if constexpr (EPI & EPI_RESID16) {
+            const u32x2 q = res16[slot][it];
+            v[0] += from_h16<F16>((h16)(q[0] & 0xffffu)); v[1] += from_h16<F16>((h16)(q[0] >> 16));
+            v[2] += from_h16<F16>((h16)(q[1] & 0xffffu)); v[3] += from_h16<F16>((h16)(q[1] >> 16));
+          }
+          if constexpr (EPI & EPI_RESID) {
+            const u32x4 q = res32[slot][it];
+            v[0] += __uint_as_float(q[0]); v[1] += __uint_as_float(q[1]);
+            v[2] += __uint_as_float(q[2]); v[3] += __uint_as_float(q[3]);
+          }
+          const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, e == OOB ? OOB : e * 4u, 0, 0);
+        } else {
+          const u32x4 o = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, e == OOB ? OOB : e * 2u, 0, 0);
+        }
+      }
+    }
   }
 #undef VTC_KTILE
 }

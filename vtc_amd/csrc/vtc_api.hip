@@ -198,7 +198,9 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
   // Tile choice (measured with tools/gemm_bench): the persistent 256 x BN kernel needs N % BN == 0 and
   // K % 128 == 0; BN = 256 where N allows (conv 512, QKV 2304, FFN1 3072), BN = 192 for N = 768.
-  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.M >= 4096) {
+  // the persistent kernel's epilogue addresses C through 32-bit buffer offsets
+  const bool fits32 = (long long)p.M * p.ldc * ((EPI & EPI_F32) ? 4 : 2) < (1ll << 31);
+  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.M >= 4096 && fits32) {
     // rounds of tiles over the 256 CUs x tile width ~ time; BN = 192 only when clearly fewer (N = 768: 2 x 192 vs 2 x 256)
     const long long tm = (p.M + 255) / 256;
     const long long c256 = p.N % 256 == 0 ? ((tm * (p.N / 256) * nz + 255) / 256) * 256 : -1;
