@@ -9,7 +9,7 @@
 
 and the same resume rule (a uid present in ANY vtc_meta/shard_*.parquet is skipped, vtc.py:158-173).
 
-What differs is where the work runs: audio decode is prefetched on host threads while the GPU works, the
+What differs is where the work runs: audio decode and the H2D copy run on reader threads while the GPU works, the
 whole forward runs in libvtc_amd.so, and threshold -> run-length decoding + the sigmoid summary happen on
 the GPU before anything is copied back (the reference does `.cpu()` first, vtc.py:252-281).
 
@@ -24,6 +24,7 @@ import argparse
 import logging
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -49,6 +50,8 @@ from ..utils import (SEGMENT_SCHEMA, add_sample_argument, atomic_write_parquet, 
 
 logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
 logger = logging.getLogger("vtc")
+
+_TLS = threading.local()
 
 # VRAM -> windows per forward pass; same table as the reference (src/pipeline/resources.py:180-188).
 _BATCH_TABLE = [(80, 512), (48, 256), (32, 192), (24, 128), (16, 64), (0, 32)]
@@ -84,22 +87,53 @@ def _unique_by_uid_keep_last(table: pa.Table) -> pa.Table:
     return table.take(pa.array(sorted(last.values())))
 
 
-def process_file(engine, wav: np.ndarray, uid: str, threshold: float, labels, batch_size: int, save_to: Path | None):
-    """One file through the fused GPU path -> (segment rows, meta row)."""
+def stage_audio(path, device: torch.device) -> torch.Tensor:
+    """Reader-thread stage: decode one file and put it in HBM on this thread's own copy stream, so that the
+    H2D transfer of file i+1 overlaps the forward of file i.  Returns only after the copy has landed."""
+    wav = read_audio(path)
     if wav.shape[0] < RF_SIZE:
         raise ValueError(f"audio too short: {wav.shape[0]} samples < receptive field {RF_SIZE}")
     host = torch.from_numpy(wav)
-    gpu = host.pin_memory().to(engine.device, non_blocking=True) if host.numel() >= (1 << 20) else host.to(engine.device)
-    logits = engine.infer_waveform(gpu, batch_size)
-    lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
-    starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
+    if host.numel() < (1 << 20):
+        return host.to(device)
+    copy_stream = getattr(_TLS, "stream", None)
+    if copy_stream is None:
+        copy_stream = _TLS.stream = torch.cuda.Stream(device)
+    with torch.cuda.stream(copy_stream):
+        gpu = host.pin_memory().to(device, non_blocking=True)
+    copy_stream.synchronize()
+    return gpu
+
+
+def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logits: bool):
+    """GPU-thread stage: forward + threshold/run-length decode; only the decoded triples (and, on request, the
+    logits) come back to the host."""
+    gpu_wav.record_stream(torch.cuda.current_stream(engine.device))
+    with torch.no_grad():
+        logits = engine.infer_waveform(gpu_wav, batch_size)
+        starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
+        cpu_logits = logits.cpu() if want_logits else None
+    return starts, ends, lab, max_logit, mean_sig, int(gpu_wav.numel()), cpu_logits
+
+
+def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
+    """Host stage: triples -> segment rows + meta row (reference vtc.py:252-281)."""
+    starts, ends, lab, max_logit, mean_sig, _, cpu_logits = decoded
     if save_to is not None:
-        cpu = logits.cpu()
-        torch.save({labels[j]: cpu[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
+        torch.save({labels[j]: cpu_logits[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
     intervals = [(int(s), int(e), labels[int(k)]) for s, e, k in zip(starts, ends, lab)]
     segs = intervals_to_segments(intervals, uid)
     max_sig = round(float(torch.sigmoid(torch.tensor(max_logit, dtype=torch.float32)).item()), 4)
     return segs, vtc_meta_row(uid, threshold, segs, max_sig, round(float(mean_sig), 4))
+
+
+def process_file(engine, wav: np.ndarray, uid: str, threshold: float, labels, batch_size: int, save_to: Path | None):
+    """One in-memory waveform through the fused GPU path -> (segment rows, meta row), synchronously."""
+    if wav.shape[0] < RF_SIZE:
+        raise ValueError(f"audio too short: {wav.shape[0]} samples < receptive field {RF_SIZE}")
+    lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
+    decoded = gpu_stage(engine, torch.from_numpy(wav).to(engine.device), lo, hi, batch_size, save_to is not None)
+    return finish_file(decoded, uid, threshold, labels, save_to)
 
 
 def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
@@ -188,14 +222,26 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     n_errors, bytes_done, audio_seconds = 0, 0, 0.0
     t0 = last_log = time.time()
     log_every = max(1, total // 20)
-    with ThreadPoolExecutor(max_workers=max(1, prefetch)) as pool:
+    # Three overlapped stages: reader threads (decode + H2D on their own streams) -> one GPU thread (forward +
+    # decode, in manifest order) -> this thread (segment rows, meta rows).  Per-file failures at any stage
+    # become error rows and the run continues (reference vtc.py:245-249).
+    lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
+    depth = max(1, prefetch)
+    save_to = logits_dir if save_logits else None
+
+    def gpu_job(audio_future):
+        torch.cuda.set_device(engine.device)
+        return gpu_stage(engine, audio_future.result(), lo, hi, batch_size, save_logits)
+
+    with ThreadPoolExecutor(max_workers=depth) as readers, ThreadPoolExecutor(max_workers=1) as gpu_thread:
         pending = {}
         nxt = 0
 
         def top_up():
             nonlocal nxt
-            while nxt < total and len(pending) < max(1, prefetch):
-                pending[nxt] = pool.submit(read_audio, uid_to_path[todo[nxt]])
+            while nxt < total and len(pending) < depth + 1:
+                audio = readers.submit(stage_audio, uid_to_path[todo[nxt]], engine.device)
+                pending[nxt] = gpu_thread.submit(gpu_job, audio)
                 nxt += 1
 
         top_up()
@@ -203,11 +249,9 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             fut = pending.pop(i)
             top_up()
             try:
-                wav = fut.result()
-                with torch.no_grad():
-                    segs, row = process_file(engine, wav, uid, threshold, labels, batch_size,
-                                             logits_dir if save_logits else None)
-                audio_seconds += wav.shape[0] / 16000.0
+                decoded = fut.result()
+                segs, row = finish_file(decoded, uid, threshold, labels, save_to)
+                audio_seconds += decoded[5] / 16000.0
             except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
                 n_errors += 1
                 logger.warning(f"{uid}: {e}")
