@@ -115,8 +115,10 @@ int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t n_windows, float* o
 int vtc_debug_stop_after(vtc_model* m, int32_t stage);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py roofline object).
- * vtc_profile_enable(m,1) starts recording every launch; vtc_profile_read synchronises, sums the
- * recorded launches per class and resets.  Classes: see vtc_profile_class_name. */
+ * vtc_profile_enable(m,1) starts (or resumes) recording every launch, (m,0) pauses it and keeps what was
+ * recorded, so a caller can sample some steps of a timed region; vtc_profile_read synchronises, sums the
+ * recorded launches per class and resets.  Two event records per launch cost about 7 us of stream time.
+ * Classes: see vtc_profile_class_name. */
 #define VTC_PROF_CLASSES 8
 int vtc_profile_enable(vtc_model* m, int32_t on);
 int vtc_profile_read(vtc_model* m, double* ms /*[VTC_PROF_CLASSES]*/, int64_t* launches /*[VTC_PROF_CLASSES]*/,

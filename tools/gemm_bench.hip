@@ -27,15 +27,20 @@ template <int EPI> void run(const Shape& s, GemmParams p, int which, hipStream_t
 
 int main(int argc, char** argv) {
   int iters = argc > 1 ? atoi(argv[1]) : 10;
+  const char* only = argc > 2 ? argv[2] : "";      // substring filter on the shape name
+  const int only_tile = argc > 3 ? atoi(argv[3]) : 0;
   std::vector<Shape> shapes = {
       {"conv1  M=1.02M N=512  K=1536 (implicit)", 64 * 15999, 512, 1536, 15999, 1024, 31999LL * 512, EPI_GELU},
       {"conv2  M=512K  N=512  K=1536 (implicit)", 64 * 7999, 512, 1536, 7999, 1024, 15999LL * 512, EPI_GELU},
       {"conv5  M=64K   N=512  K=1024 (implicit)", 64 * 999, 512, 1024, 999, 1024, 1999LL * 512, EPI_GELU},
       {"qkv    M=31936 N=2304 K=768", 31936, 2304, 768, 31936, 768, 0, EPI_BIAS},
-      {"oproj  M=31936 N=768  K=768  (+resid f32)", 31936, 768, 768, 31936, 768, 0, EPI_BIAS | EPI_RESID | EPI_F32},
+      {"oproj  M=31936 N=768  K=768  (+resid16)  ", 31936, 768, 768, 31936, 768, 0, EPI_BIAS | EPI_RESID16 | EPI_F32},
       {"ffn1   M=31936 N=3072 K=768  (gelu)", 31936, 3072, 768, 31936, 768, 0, EPI_BIAS | EPI_GELU},
-      {"ffn2   M=31936 N=768  K=3072 (+resid f32)", 31936, 768, 3072, 31936, 3072, 0, EPI_BIAS | EPI_RESID | EPI_F32},
+      {"ffn1'  M=31936 N=3072 K=768  (bias only)", 31936, 3072, 768, 31936, 768, 0, EPI_BIAS},
+      {"qkv'   M=31936 N=2304 K=768  (gelu)", 31936, 2304, 768, 31936, 768, 0, EPI_BIAS | EPI_GELU},
+      {"ffn2   M=31936 N=768  K=3072 (+resid16)  ", 31936, 768, 3072, 31936, 3072, 0, EPI_BIAS | EPI_RESID16 | EPI_F32},
       {"square M=8192  N=8192 K=8192", 8192, 8192, 8192, 8192, 8192, 0, EPI_BIAS},
+      {"sq4096 M=4096  N=4096 K=4096", 4096, 4096, 4096, 4096, 4096, 0, EPI_BIAS},
   };
   size_t maxA = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) {
@@ -56,16 +61,18 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& s : shapes) {
+    if (!strstr(s.name, only)) continue;
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.bias = bias; p.resid = R; p.M = s.M; p.N = s.N; p.K = s.K; p.ldc = s.N;
     p.rows_per_batch = s.rows_per_batch; p.a_row_stride = s.row_stride; p.a_batch_stride = s.batch_stride;
     for (int which : {128, 256, 192}) {
+      if (only_tile && which != only_tile) continue;
       auto go = [&]() {
         switch (s.epi) {
           case EPI_GELU: run<EPI_GELU>(s, p, which, st); break;
           case EPI_BIAS: run<EPI_BIAS>(s, p, which, st); break;
           case EPI_BIAS | EPI_GELU: run<EPI_BIAS | EPI_GELU>(s, p, which, st); break;
-          default: run<EPI_BIAS | EPI_RESID | EPI_F32>(s, p, which, st); break;
+          default: run<EPI_BIAS | EPI_RESID16 | EPI_F32>(s, p, which, st); break;
         }
       };
       go(); go();
@@ -77,6 +84,21 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       ms /= iters;
       printf("%-46s tile %4d  %8.3f ms  %7.1f TFLOP/s\n", s.name, which, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+#ifdef VTC_STAMPS
+      if (which != 128) {
+        std::vector<long long> h(256 * 8);
+        CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
+        double d[7] = {0, 0, 0, 0, 0, 0, 0}; int n = 0;
+        for (int b = 0; b < 256; ++b) {
+          const long long* t = &h[b * 8];
+          if (!t[7]) continue;   // block ran fewer than two tiles
+          for (int k = 0; k < 7; ++k) d[k] += (double)(t[k + 1] - t[k]);
+          ++n;
+        }
+        if (n) printf("    stamps (cycles, mean of %d blocks): loop0 %.0f  prologue-issue %.0f  epilogue %.0f  wait+barrier %.0f  loop1 %.0f  "
+                      "prologue-issue %.0f  epilogue %.0f\n", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n);
+      }
+#endif
     }
   }
   return 0;

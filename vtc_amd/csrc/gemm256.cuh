@@ -9,7 +9,7 @@
 //
 // Structure (cdna_hip_programming.md section 5, "The 256^2 8-phase template"):
 //   * LDS: 2 K-tile buffers x 4 half-tiles (A0,B0,B1,A1; 128 rows x 128 B each, B1 64 rows when BN = 192),
-//     XOR-swizzled; plus a separate 32 KiB epilogue region (8 waves x 16 rows x 64 fp32).
+//     XOR-swizzled.
 //   * a wave (wm 0..1, wn 0..3) owns rows {h*128 + wm*64 ..+64}, h = 0,1, and cols {wn*32 ..+32} of B0 plus
 //     {wn*NB1 ..} of B1, so its four quadrants consume the half-tiles in the order they are staged.
 //   * every phase: ds_read the fragments it needs, issue ONE half-tile of global_load_lds prefetch,
@@ -17,8 +17,12 @@
 //     COUNT (3 half-tiles stay in flight across the barriers), never 0 in steady state.
 //   * a slot is restaged at least one full phase after its last ds_read; a staged tile is first read one
 //     phase after the wait + barrier that retired it.
+//   * the MFMAs compute C^T (W fragment as the A operand): a lane then holds ONE output row and, per 16 x 16
+//     tile, 4 consecutive output columns.  W rows are staged into LDS in a permuted order (perm32 below) so
+//     that the two tiles of a 32-column group give a lane 8 consecutive columns: the epilogue needs no LDS
+//     transpose and stores 16 B per lane straight from the accumulators.
 //   * persistent: a block walks tiles b, b+G, b+2G, ...; the NEXT tile's prologue loads are issued before
-//     the current tile's epilogue, which runs out of its own LDS region, so loads and stores overlap.
+//     the current tile's epilogue (registers only), so loads and stores overlap.
 #pragma once
 #include "common.cuh"
 #include "gemm.cuh"
@@ -26,7 +30,20 @@
 namespace vtc {
 
 constexpr int kHalfBytes = 128 * 128;  // one full half-tile: 128 rows x 64 elements x 2 B
-constexpr int kEpiRegion = 8 * 4096;   // 8 waves x (16 rows x 64 fp32)
+
+// LDS row rho (0..31) of a 32-row group of W holds W row perm32(rho): MFMA tile j = rho>>4, operand row
+// i' = rho&15 lands in accumulator (quad i'>>2, reg i'&3) and is output column 8*(i'>>2) + 4*j + (i'&3).
+__device__ __forceinline__ int perm32(int rho) { return 8 * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3); }
+
+#ifndef VTC_STORE_AUX
+#define VTC_STORE_AUX 0   // cache policy bits of the epilogue stores (tools/gemm_bench builds try others)
+#endif
+#ifdef VTC_STAMPS   // tools/gemm_bench diagnostic build: s_memtime stamps of the first two tiles of every block
+__device__ long long g_stamps[256 * 8];
+#define VTC_STAMP(k) do { if (tile_it < 2) st[tile_it * 4 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VTC_STAMP(k) do { } while (0)
+#endif
 
 template <int BN>
 struct Tile256 {
@@ -37,13 +54,14 @@ struct Tile256 {
   static constexpr int OFF_A0 = 0, OFF_B0 = kHalfBytes, OFF_B1 = 2 * kHalfBytes;
   static constexpr int OFF_A1 = OFF_B1 + B1_ROWS * 128;
   static constexpr int BUF = OFF_A1 + kHalfBytes;
-  static constexpr int SMEM = 2 * BUF + kEpiRegion;
+  static constexpr int SMEM = 2 * BUF;
 };
 
 template <bool F16, int EPI, int BN>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   using TC = Tile256<BN>;
   constexpr int NJ1 = TC::NJ1;
+  static_assert(!(EPI & EPI_RESID), "fp32 residual is not supported here (the encoder keeps a 16-bit residual stream)");
   __shared__ __attribute__((aligned(16))) char smem[TC::SMEM];
 
   const int tid = threadIdx.x;
@@ -76,13 +94,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
                                              (long long)rr * p.a_row_stride + sw));
         if (h) src_a1[i] = a; else src_a0[i] = a;
       }
-      src_b0[i] = (const char*)(p.W + ((long long)z * p.w_z_stride + ((long long)tile_n * BN + r) * p.K + sw));
+      const int wr = (r & ~31) + perm32(r & 31);
+      src_b0[i] = (const char*)(p.W + ((long long)z * p.w_z_stride + ((long long)tile_n * BN + wr) * p.K + sw));
     }
 #pragma unroll
     for (int i = 0; i < NJ1; ++i) {
       const int r = (wave * NJ1 + i) * 8 + lr;  // row inside the B1 half-tile
       const long long sw = (long long)((lc ^ lds_swz(r)) * 8);
-      src_b1[i] = (const char*)(p.W + ((long long)z * p.w_z_stride + ((long long)tile_n * BN + 128 + r) * p.K + sw));
+      const int wr = NJ1 == 2 ? (r & ~31) + perm32(r & 31) : r;   // 16-column groups need no permutation
+      src_b1[i] = (const char*)(p.W + ((long long)z * p.w_z_stride + ((long long)tile_n * BN + 128 + wr) * p.K + sw));
     }
   };
 
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc0[mq][i][j] = mfma16<F16>(fa[ks][i], fb0[ks][j], acc0[mq][i][j]);
+        for (int j = 0; j < 2; ++j) acc0[mq][i][j] = mfma16<F16>(fb0[ks][j], fa[ks][i], acc0[mq][i][j]);
     __builtin_amdgcn_s_setprio(0);
   };
   auto mma1 = [&](int mq) {
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ1; ++j) acc1[mq][i][j] = mfma16<F16>(fa[ks][i], fb1[ks][j], acc1[mq][i][j]);
+        for (int j = 0; j < NJ1; ++j) acc1[mq][i][j] = mfma16<F16>(fb1[ks][j], fa[ks][i], acc1[mq][i][j]);
     __builtin_amdgcn_s_setprio(0);
   };
   auto sync_reads = [&]() {
@@ -171,12 +191,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
-  auto prologue = [&]() {  // all of K-tile 0, A0 + B0 of K-tile 1 (4 glds stay in flight at the first wait)
+  auto prologue = [&]() {  // first tile of the block only: all of K-tile 0, A0 + B0 of K-tile 1 (the steady state)
     issue_a0(0, 0); issue_b0(0, 0); issue_b1(0, 0); issue_a1(0, 0);
     issue_a0(1, 1); issue_b0(1, 1);
   };
 
-  const int nk = p.K >> 6;  // even, >= 2
+  const int nk = p.K >> 6;  // even, >= 4
   const unsigned G = gridDim.x;
   unsigned tl = blockIdx.x;
   {
@@ -188,31 +208,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // Staging order per K-tile T (one half-tile per phase): B1(T+1), A1(T+1), A0(T+2), B0(T+2).  Every slot is
   // restaged >= 2 phases after its last ds_read, which is what the half-phase stagger between the two wave
   // rows (below) needs; at the K-tile boundary wait A0(T+2) and B0(T+2) (4 glds) stay in flight.
-#define VTC_KTILE(BUF, T)                                                                                  \
+  // The pipeline runs on ACROSS tiles: in the last two K-tiles of a tile, "T+1" / "T+2" are K-tiles 0 and 1 of
+  // the block's next tile (HOOK switches the source pointers between phases 2 and 3 of K-tile nk-2), so a
+  // tile ends in exactly the state the next one starts from and there is no per-tile load burst or ramp.
+#define VTC_KTILE(BUF, C1, K1, C2, K2, HOOK)                                                               \
   {                                                                                                        \
     /* phase 1: quadrant (0, B0); reads A0,B0 */                                                           \
     read_b0(BUF);                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     read_a(BUF, TC::OFF_A0);                                                                               \
-    if ((T) + 1 < nk) issue_b1((BUF) ^ 1, (T) + 1);                                                        \
+    if (C1) issue_b1((BUF) ^ 1, (K1));                                                                     \
     sync_reads();                                                                                          \
     mma0(0);                                                                                               \
     end_phase();                                                                                           \
     /* phase 2: quadrant (0, B1); reads B1 */                                                              \
     read_b1(BUF);                                                                                          \
-    if ((T) + 1 < nk) issue_a1((BUF) ^ 1, (T) + 1);                                                        \
+    if (C1) issue_a1((BUF) ^ 1, (K1));                                                                     \
     sync_reads();                                                                                          \
     mma1(0);                                                                                               \
     end_phase();                                                                                           \
+    HOOK;                                                                                                  \
     /* phase 3: quadrant (1, B1); reads A1 */                                                              \
     read_a(BUF, TC::OFF_A1);                                                                               \
-    if ((T) + 2 < nk) issue_a0(BUF, (T) + 2);                                                              \
+    if (C2) issue_a0(BUF, (K2));                                                                           \
     sync_reads();                                                                                          \
     mma1(1);                                                                                               \
     end_phase();                                                                                           \
     /* phase 4: quadrant (1, B0); registers only; K-tile boundary wait */                                  \
-    if ((T) + 2 < nk) {                                                                                    \
-      issue_b0(BUF, (T) + 2);                                                                              \
+    if (C2) {                                                                                              \
+      issue_b0(BUF, (K2));                                                                                 \
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                     \
     } else {                                                                                               \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
@@ -223,7 +247,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     end_phase();                                                                                           \
   }
 
-  float* epi = (float*)(smem + 2 * TC::BUF + wave * 4096);
+  bool first_tile = true;
+#ifdef VTC_STAMPS
+  long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int tile_it = 0;
+#endif
 
   while (tl < ntiles) {
     const unsigned tcur = xcd_remap(tl, ntiles);
@@ -240,144 +268,159 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         for (int j = 0; j < NJ1; ++j) acc1[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 
-    // this tile's prologue loads (and the previous tile's epilogue stores) must have landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (first_tile) {   // later tiles arrive here in the steady state (see VTC_KTILE)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      first_tile = false;
+    }
+    VTC_STAMP(0);
+    const unsigned tl_next = tl + G;
+    const bool has_next = tl_next < ntiles;
 
     // Stagger: wave row 1 (waves 4-7, the SIMD partners of waves 0-3) runs one barrier behind, so that on
     // every SIMD one wave is in its MFMA cluster while its partner reads LDS / issues loads.
     if (wm == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 2) {
-      VTC_KTILE(0, t)
-      VTC_KTILE(1, t + 1)
+    for (int t = 0; t + 2 < nk; t += 2) {
+      VTC_KTILE(0, true, t + 1, true, t + 2, )
+      VTC_KTILE(1, true, t + 2, true, t + 3, )
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();
-
-    // every wave is past its last ds_read (final barrier): stage the NEXT tile before this tile's epilogue
-    tl += G;
-    if (tl < ntiles) {
-      const unsigned tn = xcd_remap(tl, ntiles);
+    VTC_KTILE(0, true, nk - 1, has_next, 0, if (has_next) {
+      const unsigned tn = xcd_remap(tl_next, ntiles);
       set_sources((int)(tn / (unsigned)p.tiles_n), (int)(tn % (unsigned)p.tiles_n));
-      prologue();
-    }
+    })
+    VTC_KTILE(1, has_next, 0, has_next, 1, )
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    VTC_STAMP(1);
+    tl = tl_next;
+    VTC_STAMP(2);
 
-    // ---- epilogue: 8 passes of 16 rows x (32 + 16*NJ1) cols through the wave's private LDS region.
-    // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.  LDS image [16][64] fp32, the
-    // 16-B chunk index XORed with (row>>2)<<2 so that the four row groups of a write hit different banks.
+    // ---- epilogue, registers only.  C^T accumulators: lane (fr, fq) owns output row i*16 + fr of each 16-row
+    // group and columns 8*fq .. +8 of its B0 group (acc0[..][j=0,1][r]) plus 8*fq .. +8 (BN = 256) or
+    // 4*fq .. +4 (BN = 192) of its B1 group.  Global accesses go through buffer descriptors: rows outside the
+    // matrix get the offset 0x80000000 and the hardware drops the access (loads return 0), so there are no
+    // branches and vmcnt stays countable.  The residual of the whole tile is fetched before the first store.
     const int ccol_z = z * p.c_col_z;
-    // Global accesses go through buffer descriptors: lanes outside the matrix get the offset 0x80000000 and the
-    // hardware drops the access (loads return 0), so the epilogue has no branches and vmcnt stays countable.
     constexpr int ESZ = (EPI & EPI_F32) ? 4 : 2;
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int W1 = 4 * NJ1;   // columns per lane in the B1 group
     const __amdgpu_buffer_rsrc_t rc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)((long long)p.M * p.ldc * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.resid, 0, (EPI & (EPI_RESID | EPI_RESID16)) ? (int)((long long)p.M * p.ldc * ((EPI & EPI_RESID16) ? 2 : 4)) : 0,
-        0x00020000);
-    // per-lane output columns and bias (fp32 out: 4 columns per lane; 16-bit out: 8 columns per lane)
-    constexpr int CPL = (EPI & EPI_F32) ? 4 : 8;
-    constexpr int NIT = (EPI & EPI_F32) ? 4 : 2;          // row iterations per 16-row pass
-    constexpr int RPI = 16 / NIT;                         // rows per iteration
-    const int lrow = (EPI & EPI_F32) ? (lane >> 4) : (lane >> 3);
-    const int lch = (EPI & EPI_F32) ? (lane & 15) : (lane & 7);
-    const int c0 = lch * CPL;
-    const int col = tile_n * BN + (c0 < 32 ? wn * 32 + c0 : 128 + wn * (16 * NJ1) + (c0 - 32));
-    const bool col_ok = c0 < 32 + 16 * NJ1;
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        (void*)p.resid, 0, (EPI & EPI_RESID16) ? (int)((long long)p.M * p.ldc * 2) : 0, 0x00020000);
+    const int col0 = ccol_z + tile_n * BN + wn * 32 + 8 * fq;
+    const int col1 = ccol_z + tile_n * BN + 128 + wn * (16 * NJ1) + W1 * fq;
+    float bv0[8], bv1[W1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv0[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < W1; ++k) bv1[k] = 0.f;
     if constexpr (EPI & EPI_BIAS) {
-      const float4 b0 = *(const float4*)(p.bias + ccol_z + (col_ok ? col : 0));
-      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-      if constexpr (CPL == 8) {
-        const float4 b1 = *(const float4*)(p.bias + ccol_z + (col_ok ? col : 0) + 4);
-        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 b = *(const float4*)(p.bias + col0 + 4 * q);
+        bv0[4 * q] = b.x; bv0[4 * q + 1] = b.y; bv0[4 * q + 2] = b.z; bv0[4 * q + 3] = b.w;
+      }
+#pragma unroll
+      for (int q = 0; q < NJ1; ++q) {
+        const float4 b = *(const float4*)(p.bias + col1 + 4 * q);
+        bv1[4 * q] = b.x; bv1[4 * q + 1] = b.y; bv1[4 * q + 2] = b.z; bv1[4 * q + 3] = b.w;
       }
     }
-    auto elem_index = [&](int pass, int it) -> unsigned {   // element index of this lane's first column, or OOB
-      const int row = tile_m * 256 + (pass >> 2) * 128 + wm * 64 + (pass & 3) * 16 + it * RPI + lrow;
-      return (row < p.M && col_ok) ? (unsigned)(row * p.ldc + ccol_z + col) : OOB;
-    };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // residual of the NEXT pass is fetched before this pass's stores are issued (one pass of prefetch)
-    u32x2 res16[2][4];
-    u32x4 res32[2][4];
-    auto fetch_resid = [&](int pass, int slot) {
-      if constexpr (EPI & EPI_RESID16) {
+    unsigned rowoff[8];   // element offset of (row, column 0 of the z slice), or OOB
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const unsigned e = elem_index(pass, it);
-          res16[slot][it] = __builtin_amdgcn_raw_buffer_load_b64(rr, e == OOB ? OOB : e * 2u, 0, 0);
-        }
-      }
-      if constexpr (EPI & EPI_RESID) {
+    for (int g = 0; g < 8; ++g) {
+      const int row = tile_m * 256 + (g >> 2) * 128 + wm * 64 + (g & 3) * 16 + fr;
+      rowoff[g] = row < p.M ? (unsigned)(row * p.ldc) : OOB;
+    }
+#ifdef VTC_ABL_NOSTORE   // tools/gemm_bench ablation: every store is dropped by the bounds check
+#define VTC_OFF_ST(g, col, sz) OOB
+#else
+#define VTC_OFF_ST(g, col, sz) (rowoff[g] == OOB ? OOB : (rowoff[g] + (unsigned)(col)) * (sz))
+#endif
+#define VTC_OFF_LD(g, col, sz) (rowoff[g] == OOB ? OOB : (rowoff[g] + (unsigned)(col)) * (sz))
+    u32x4 res0[8];
+    u32x4 res1[8];
+    if constexpr (EPI & EPI_RESID16) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const unsigned e = elem_index(pass, it);
-          res32[slot][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, e == OOB ? OOB : e * 4u, 0, 0);
-        }
-      }
-    };
-    fetch_resid(0, 0);
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int mq = pass >> 2, i = pass & 3, slot = pass & 1;
-      if (pass + 1 < 8) fetch_resid(pass + 1, slot ^ 1);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = fq * 4 + r;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int c = j * 16 + fr;
-          epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc0[mq][i][j][r];
-        }
-#pragma unroll
-        for (int j = 0; j < NJ1; ++j) {
-          const int c = 32 + j * 16 + fr;
-          epi[row * 64 + ((((c >> 2) ^ (fq << 2)) << 2) | (c & 3))] = acc1[mq][i][j][r];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int r = it * RPI + lrow;
-        const int sw = (r >> 2) << 2;
-        const unsigned e = elem_index(pass, it);
-        float v[8];
-        if constexpr (EPI & EPI_F32) {
-          const float4 x = *(const float4*)(epi + r * 64 + ((lch ^ sw) << 2));
-          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+      for (int g = 0; g < 8; ++g) {
+        res0[g] = __builtin_amdgcn_raw_buffer_load_b128(rr, VTC_OFF_LD(g, col0, 2u), 0, 0);
+        if constexpr (NJ1 == 2) {
+          res1[g] = __builtin_amdgcn_raw_buffer_load_b128(rr, VTC_OFF_LD(g, col1, 2u), 0, 0);
         } else {
-          const float4 x0 = *(const float4*)(epi + r * 64 + (((2 * lch) ^ sw) << 2));
-          const float4 x1 = *(const float4*)(epi + r * 64 + (((2 * lch + 1) ^ sw) << 2));
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        }
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-          v[k] += bv[k];
-          if constexpr (EPI & EPI_GELU) v[k] = gelu_f(v[k]);
-        }
-        if constexpr (EPI & EPI_F32) {
-          if constexpr (EPI & EPI_RESID16) {
-            const u32x2 q = res16[slot][it];
-            v[0] += from_h16<F16>((h16)(q[0] & 0xffffu)); v[1] += from_h16<F16>((h16)(q[0] >> 16));
-            v[2] += from_h16<F16>((h16)(q[1] & 0xffffu)); v[3] += from_h16<F16>((h16)(q[1] >> 16));
-          }
-          if constexpr (EPI & EPI_RESID) {
-            const u32x4 q = res32[slot][it];
-            v[0] += __uint_as_float(q[0]); v[1] += __uint_as_float(q[1]);
-            v[2] += __uint_as_float(q[2]); v[3] += __uint_as_float(q[3]);
-          }
-          const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rc, e == OOB ? OOB : e * 4u, 0, 0);
-        } else {
-          const u32x4 o = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rc, e == OOB ? OOB : e * 2u, 0, 0);
+          const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rr, VTC_OFF_LD(g, col1, 2u), 0, 0);
+          res1[g] = u32x4{t[0], t[1], 0u, 0u};
         }
       }
     }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int mq = g >> 2, i = g & 3;
+      float v0[8], v1[W1];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v0[4 * j + r] = acc0[mq][i][j][r] + bv0[4 * j + r];
+#pragma unroll
+      for (int j = 0; j < NJ1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v1[4 * j + r] = acc1[mq][i][j][r] + bv1[4 * j + r];
+      if constexpr (EPI & EPI_GELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v0[k] = gelu_f(v0[k]);
+#pragma unroll
+        for (int k = 0; k < W1; ++k) v1[k] = gelu_f(v1[k]);
+      }
+      if constexpr (EPI & EPI_RESID16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v0[2 * k] += from_h16<F16>((h16)(res0[g][k] & 0xffffu));
+          v0[2 * k + 1] += from_h16<F16>((h16)(res0[g][k] >> 16));
+        }
+#pragma unroll
+        for (int k = 0; k < W1 / 2; ++k) {
+          v1[2 * k] += from_h16<F16>((h16)(res1[g][k] & 0xffffu));
+          v1[2 * k + 1] += from_h16<F16>((h16)(res1[g][k] >> 16));
+        }
+      }
+      if constexpr (EPI & EPI_F32) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 o = {__float_as_uint(v0[4 * q]), __float_as_uint(v0[4 * q + 1]), __float_as_uint(v0[4 * q + 2]),
+                           __float_as_uint(v0[4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, VTC_OFF_ST(g, col0 + 4 * q, 4u), 0, VTC_STORE_AUX);
+        }
+#pragma unroll
+        for (int q = 0; q < NJ1; ++q) {
+          const u32x4 o = {__float_as_uint(v1[4 * q]), __float_as_uint(v1[4 * q + 1]), __float_as_uint(v1[4 * q + 2]),
+                           __float_as_uint(v1[4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, VTC_OFF_ST(g, col1 + 4 * q, 4u), 0, VTC_STORE_AUX);
+        }
+      } else {
+        const u32x4 o0 = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v0[4], v0[5]), pack2<F16>(v0[6], v0[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rc, VTC_OFF_ST(g, col0, 2u), 0, VTC_STORE_AUX);
+        if constexpr (NJ1 == 2) {
+          const u32x4 o1 = {pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3]), pack2<F16>(v1[4], v1[5]), pack2<F16>(v1[6], v1[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(o1, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
+        } else {
+          const u32x2 o1 = {pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(o1, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
+        }
+      }
+    }
+#undef VTC_OFF_ST
+#undef VTC_OFF_LD
+    VTC_STAMP(3);
+#ifdef VTC_STAMPS
+    ++tile_it;
+#endif
   }
 #undef VTC_KTILE
+#ifdef VTC_STAMPS
+  if (tid == 0 && blockIdx.y == 0)
+    for (int k = 0; k < 8; ++k) g_stamps[blockIdx.x * 8 + k] = st[k];
+#endif
 }
 
 template <bool F16, int EPI, int BN>
@@ -385,7 +428,11 @@ inline void launch_gemm256(GemmParams p, int nz, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / BN;
   const int ntiles = p.tiles_m * p.tiles_n;
-  dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), (unsigned)nz);
+  int cap = 256;
+#ifdef VTC_STAMPS
+  if (const char* e = getenv("VTC_GRID")) cap = atoi(e);   // diagnostic: run on a subset of the CUs
+#endif
+  dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), (unsigned)nz);
   hipLaunchKernelGGL((gemm256_kernel<F16, EPI, BN>), grid, dim3(512), 0, s, p);
 }
 

@@ -197,15 +197,16 @@ template <bool F16, int BN, int EPI>
 void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
   // Tile choice (measured with tools/gemm_bench): the persistent 256 x BN kernel needs N % BN == 0 and
-  // K % 128 == 0; BN = 256 where N allows (conv 512, QKV 2304, FFN1 3072), BN = 192 for N = 768.
+  // K % 128 == 0 (>= 256); BN = 192 where N allows and its rounds x width are no worse (N = 768, 2304, 3072:
+  // the 192-wide kernel has no register spills and a cheaper epilogue), BN = 256 otherwise (conv, N = 512).
   // the persistent kernel's epilogue addresses C through 32-bit buffer offsets
   const bool fits32 = (long long)p.M * p.ldc * ((EPI & EPI_F32) ? 4 : 2) < (1ll << 31);
-  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.M >= 4096 && fits32) {
-    // rounds of tiles over the 256 CUs x tile width ~ time; BN = 192 only when clearly fewer (N = 768: 2 x 192 vs 2 x 256)
+  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.K >= 256 && p.M >= 4096 && fits32) {
+    // rounds of tiles over the 256 CUs x tile width ~ time
     const long long tm = (p.M + 255) / 256;
     const long long c256 = p.N % 256 == 0 ? ((tm * (p.N / 256) * nz + 255) / 256) * 256 : -1;
     const long long c192 = p.N % 192 == 0 ? ((tm * (p.N / 192) * nz + 255) / 256) * 192 : -1;
-    if (c256 > 0 && (c192 < 0 || 10 * c192 >= 8 * c256)) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
+    if (c256 > 0 && (c192 < 0 || 100 * c192 > 102 * c256)) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
     if (c192 > 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
   }
   LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
@@ -605,9 +606,7 @@ int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t nw, float* out, int
 
 int vtc_profile_enable(vtc_model* m, int32_t on) {
   if (!m) return VTC_ERR_ARG;
-  m->prof_on = on != 0;
-  m->prof.clear();
-  m->ev_next = 0;
+  m->prof_on = on != 0;   // records are kept across pause/resume; vtc_profile_read drains them
   return VTC_OK;
 }
 
