@@ -76,6 +76,38 @@ def test_every_stage_against_oracle(weights, dtype, conv_tol, hid_tol):
     eng.close()
 
 
+@pytest.mark.parametrize("gamma_scale", [1.0, 2000.0])
+def test_conv0_quiet_loud_and_out_of_range_windows(weights, gamma_scale):
+    """conv0 + GroupNorm + GELU (stage 0) on inputs that stress the fp16-split MFMA form: a -100 dBFS window, a loud
+    window with a DC offset, and a near-silent window with one full-scale click.  With the GroupNorm weight scaled
+    by 2000 the folded operand leaves the fp16 range for some windows, which must then take the VALU form."""
+    chunk, B, W = 1.0, 3, 16000
+    rng = np.random.default_rng(7)
+    wav = np.zeros((B, W), dtype=np.float32)
+    wav[0] = rng.standard_normal(W).astype(np.float32) * np.float32(1e-5)
+    wav[1] = np.clip(rng.standard_normal(W).astype(np.float32) * np.float32(0.3) + np.float32(0.4), -1, 1)
+    wav[2] = rng.standard_normal(W).astype(np.float32) * np.float32(1e-4)
+    wav[2, 5000] = 1.0
+    w = dict(weights)
+    key = "feature_extractor.conv_layers.0.layer_norm.weight"
+    w[key] = (np.asarray(w[key]) * np.float32(gamma_scale)).astype(np.float32) if not isinstance(w[key], torch.Tensor) \
+        else w[key] * gamma_scale
+    with torch.no_grad():
+        ref = O.encoder_stages(w, torch.from_numpy(wav))["conv0"].transpose(1, 2).contiguous()
+    eng = _engine(w, chunk, B)
+    T = O.conv_out_len(W)
+    logits = torch.zeros((B * T, 4), device="cuda")
+    eng.debug_stop_after(0)
+    eng.forward_windows(torch.from_numpy(wav.reshape(-1).copy()).cuda(), np.arange(B) * W, np.full(B, W), np.arange(B) * T,
+                        np.full(B, T), logits)
+    got = torch.from_numpy(eng.debug_stage(0, B, ref.numel()).reshape(ref.shape))
+    ok = ref.abs() < 6.0e4                       # beyond that the 16-bit activation itself overflows
+    assert ok.float().mean().item() > 0.99
+    err = ((got - ref).abs() - 1.5e-3 * ref.abs())[ok].max().item()     # fp16 storage: 2^-11 relative, plus 2e-3 abs
+    assert err <= 2e-3, err
+    eng.close()
+
+
 def test_golden_logits_fixture(weights, golden_dir):
     """Committed fixture (tests/golden/encoder_1s.npz), no oracle code involved in the expected values."""
     info = json.loads((golden_dir / "golden_encoder.json").read_text())

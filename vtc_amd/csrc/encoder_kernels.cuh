@@ -22,23 +22,27 @@ struct WindowTable {          // device arrays, one entry per window of the batc
 // Accumulated in fp64, per-block partials summed in a fixed order (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatN = 65;
+constexpr int kStatSlots = 66;    // 65 moments + max |x| of the chunk (scales the fp16 split of conv0, below)
 constexpr int kStatChunk = 2048;  // conv0 frames per block
 
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
-                                                            double* __restrict__ partial /*[B][nchunk][65]*/) {
+                                                            double* __restrict__ partial /*[B][nchunk][66]*/) {
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const long long s0 = wt.start[b];
   const int valid = wt.valid[b];
   double acc[kStatN];
 #pragma unroll
   for (int i = 0; i < kStatN; ++i) acc[i] = 0.0;
+  float amax = 0.f;
   const int t_end = min(L0, (chunk + 1) * kStatChunk);
   for (int t = chunk * kStatChunk + threadIdx.x; t < t_end; t += 256) {
     double x[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       const int i = 5 * t + j;
-      x[j] = i < valid ? (double)wav[s0 + i] : 0.0;
+      const float xf = i < valid ? wav[s0 + i] : 0.f;
+      amax = fmaxf(amax, fabsf(xf));
+      x[j] = (double)xf;
     }
     int k = 10;
 #pragma unroll
@@ -48,33 +52,52 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
       for (int j2 = j; j2 < 10; ++j2) { acc[k] = fma(x[j], x[j2], acc[k]); ++k; }
     }
   }
-  __shared__ double red[4][kStatN];
+  __shared__ double red[4][kStatSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < kStatN; ++i) {
     const double v = wave_sum_d(acc[i]);
     if (lane == 0) red[wave][i] = v;
   }
+  amax = wave_max(amax);
+  if (lane == 0) red[wave][kStatN] = (double)amax;
   __syncthreads();
+  double* dst = partial + ((long long)b * nchunk + chunk) * kStatSlots;
   if (threadIdx.x < kStatN) {
     const int i = threadIdx.x;
-    partial[((long long)b * nchunk + chunk) * kStatN + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    dst[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  } else if (threadIdx.x == kStatN) {
+    dst[kStatN] = fmax(fmax(red[0][kStatN], red[1][kStatN]), fmax(red[2][kStatN], red[3][kStatN]));
   }
 }
 
 // One block per window, one thread per channel: fold the moments with the channel's 10 taps.
+//
+// For the MFMA form of conv0 (conv0_mfma_kernel) the same thread also writes the channel's row of the
+// A operand: with x' = x * 2^e (e such that max|x'| is in [8, 16)) and w' = w * scale * 2^-e,
+//   y*scale + shift = sum_j (xh_j + xl_j)(wh_j + wl_j) + shift  ~  [xh | xl | xh | 1 1] . [wh | wh | wl | sh_h sh_l]
+// where h / l are the fp16 head and tail of an fp32 number (the dropped xl*wl terms are 2^-22 relative).
+// That is ONE 32-deep fp16 MFMA per 16 x 16 outputs with fp32-level accuracy.  A window whose operand
+// would leave the fp16 range (|w'| or |shift| > 3e4: pathological weights) is flagged and takes the VALU path.
 __global__ __launch_bounds__(512) void conv0_gn_finalize_kernel(const double* __restrict__ partial, int nchunk, int L0,
                                                                 const float* __restrict__ w0 /*[512][10]*/,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
                                                                 float* __restrict__ scale /*[B][512]*/,
-                                                                float* __restrict__ shift) {
-  __shared__ double mom[kStatN];
+                                                                float* __restrict__ shift,
+                                                                _Float16* __restrict__ aop /*[B][512][32]*/,
+                                                                float* __restrict__ xscale /*[B]*/,
+                                                                int* __restrict__ valu_flag /*[B]*/) {
+  __shared__ double mom[kStatSlots];
   const int b = blockIdx.x;
   if (threadIdx.x < kStatN) {
     double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += partial[((long long)b * nchunk + c) * kStatN + threadIdx.x];
+    for (int c = 0; c < nchunk; ++c) s += partial[((long long)b * nchunk + c) * kStatSlots + threadIdx.x];
     mom[threadIdx.x] = s;
+  } else if (threadIdx.x == kStatN) {
+    double mx = 0.0;
+    for (int c = 0; c < nchunk; ++c) mx = fmax(mx, partial[((long long)b * nchunk + c) * kStatSlots + kStatN]);
+    mom[kStatN] = mx;
   }
   __syncthreads();
   const int c = threadIdx.x;
@@ -97,23 +120,46 @@ __global__ __launch_bounds__(512) void conv0_gn_finalize_kernel(const double* __
   var = var > 0.0 ? var : 0.0;
   const double rstd = 1.0 / sqrt(var + 1e-5);
   const double sc = (double)gamma[c] * rstd;
-  scale[b * 512 + c] = (float)sc;
-  shift[b * 512 + c] = (float)((double)beta[c] - mean * sc);
+  const float scf = (float)sc;
+  const float shf = (float)((double)beta[c] - mean * sc);
+  scale[b * 512 + c] = scf;
+  shift[b * 512 + c] = shf;
+
+  // fp16-split operand row.  2^e: max|x| * 2^e in [8, 16); silence keeps e = 0.
+  const float amax = (float)mom[kStatN];
+  const float p2 = amax > 0.f ? exp2f(3.f - floorf(log2f(amax))) : 1.f;
+  const float inv = 1.f / p2;   // exact, a power of two
+  bool bad = !(fabsf(shf) < 3.0e4f) || !(p2 < 1.0e30f) || !(inv < 1.0e30f);
+  _Float16 row[32];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const float wp = (float)w[j] * scf * inv;   // the product the VALU path forms as fma(y, scale, shift), here pre-scaled
+    bad = bad || !(fabsf(wp) < 3.0e4f);
+    const _Float16 h = (_Float16)wp;
+    const _Float16 l = (_Float16)(wp - (float)h);
+    row[j] = h; row[10 + j] = h; row[20 + j] = l;
+  }
+  const _Float16 sh_h = (_Float16)shf;
+  row[30] = sh_h;
+  row[31] = (_Float16)(shf - (float)sh_h);
+  _Float16* dst = aop + ((long long)b * 512 + c) * 32;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) dst[i] = row[i];
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) { xscale[b] = p2; valu_flag[b] = any_bad; }
 }
 
-// conv0 + GroupNorm affine + GELU -> channel-last (B, L0, 512) 16-bit.  Waveform tile staged in LDS,
-// each lane owns 8 adjacent channels (taps in registers) so a wave stores one 1 KiB frame row.
-constexpr int kC0Frames = 64;  // conv0 frames per block
+// conv0 + GroupNorm affine + GELU -> channel-last (B, L0, 512) 16-bit, VALU form.  Waveform tile staged in
+// LDS, each lane owns 8 adjacent channels (taps in registers) so a wave stores one 1 KiB frame row.
+// Used for bf16 operands and for windows flagged by the finalize kernel.
+constexpr int kC0Frames = 64;  // conv0 frames per VALU tile
 
 template <bool F16>
-__global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
-                                                          const float* __restrict__ w0, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, h16* __restrict__ out) {
-  __shared__ float xs[5 * kC0Frames + 8];
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * kC0Frames;
-  const long long s0 = wt.start[b];
-  const int valid = wt.valid[b];
+__device__ __forceinline__ void conv0_valu_tile(float* xs /*[5*64+8]*/, const float* __restrict__ wav, long long s0, int valid,
+                                                int b, int t0, int L0, const float* __restrict__ w0,
+                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                h16* __restrict__ out) {
+  __syncthreads();
   for (int i = threadIdx.x; i < 5 * kC0Frames + 5; i += 256) {
     const int g = 5 * t0 + i;
     xs[i] = g < valid ? wav[s0 + g] : 0.f;
@@ -149,6 +195,97 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
       pk[c >> 1] = pack2<F16>(y0, y1);
     }
     *(uint4*)(out + ((long long)b * L0 + t) * 512 + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
+                                                          const float* __restrict__ w0, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, h16* __restrict__ out) {
+  __shared__ float xs[5 * kC0Frames + 8];
+  const int b = blockIdx.y;
+  conv0_valu_tile<F16>(xs, wav, wt.start[b], wt.valid[b], b, blockIdx.x * kC0Frames, L0, w0, scale, shift, out);
+}
+
+// MFMA form (fp16 operands only; see conv0_gn_finalize_kernel for the operand split).  A block = 256 frames x
+// 512 channels of one window: the frames' B operand [xh | xl | xh | 1 1] (64 B per frame) is built once in LDS;
+// wave w owns channels [128 w, +128): 8 A fragments in registers, channels assigned to MFMA tiles so that a
+// lane ends up with 16 consecutive channels of one frame per 64-channel group (two 16-B stores).
+// Per output the VALU work left is the GELU and the fp16 pack.
+constexpr int kC0mFrames = 256;
+
+// VALU form for the windows the finalize kernel flagged (none with sane weights): 8 blocks per window walk its tiles.
+__global__ __launch_bounds__(256) void conv0_valu_fallback_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
+                                                                  const int* __restrict__ valu_flag, const float* __restrict__ w0,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  h16* __restrict__ out) {
+  __shared__ float xs[5 * kC0Frames + 8];
+  const int b = blockIdx.y;
+  if (!valu_flag[b]) return;
+  for (int t0 = blockIdx.x * kC0Frames; t0 < L0; t0 += gridDim.x * kC0Frames)
+    conv0_valu_tile<true>(xs, wav, wt.start[b], wt.valid[b], b, t0, L0, w0, scale, shift, out);
+}
+
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
+                                                         const _Float16* __restrict__ aop, const float* __restrict__ xscale,
+                                                         const int* __restrict__ valu_flag, h16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) _Float16 xp[kC0mFrames * 32];   // 16 KiB
+  __shared__ float xs[5 * kC0mFrames + 8];
+  const int b = blockIdx.y;
+  if (valu_flag[b]) return;   // block-uniform: operand outside the fp16 range, conv0_valu_fallback_kernel does this window
+  const int t0 = blockIdx.x * kC0mFrames;
+  const long long s0 = wt.start[b];
+  const int valid = wt.valid[b];
+  const float p2 = xscale[b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {   // 5 * 256 + 5 samples, independent loads
+    const int o = threadIdx.x + i * 256;
+    const int g = 5 * t0 + o;
+    if (o < 5 * kC0mFrames + 5) xs[o] = (g < valid ? wav[s0 + g] : 0.f) * p2;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kC0mFrames * 10; idx += 256) {
+    const int f = idx / 10, j = idx - f * 10;
+    const float x = xs[5 * f + j];
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    _Float16* row = xp + f * 32;
+    row[j] = h; row[10 + j] = l; row[20 + j] = h;
+    if (j < 2) row[30 + j] = (_Float16)1.0f;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  // A fragments: MFMA tile j of 64-channel group q holds channel 16*(i>>2) + 4*j + (i&3) in operand row i
+  u16x8 af[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave * 128 + q * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);
+      af[q][j] = *(const u16x8*)(aop + ((long long)b * 512 + c) * 32 + fq * 8);
+    }
+  __syncthreads();
+#pragma unroll 2
+  for (int ft = 0; ft < kC0mFrames / 16; ++ft) {
+    const int t = t0 + ft * 16 + fr;
+    const u16x8 bf = *(const u16x8*)(xp + (ft * 16 + fr) * 32 + fq * 8);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      unsigned pk[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma16<true>(af[q][j], bf, acc);   // rows: channels 16*fq' + 4j + r of the group, cols: frames
+        pk[2 * j] = pack2<true>(gelu_f(acc[0]), gelu_f(acc[1]));
+        pk[2 * j + 1] = pack2<true>(gelu_f(acc[2]), gelu_f(acc[3]));
+      }
+      if (t < L0) {
+        h16* dst = out + ((long long)b * L0 + t) * 512 + wave * 128 + q * 64 + 16 * fq;
+        *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      }
+    }
   }
 }
 
@@ -194,19 +331,25 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const h16* __restrict
   *(uint4*)(out + (long long)row * 512 + lane * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
-template <bool F16, bool HEAD>
-__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ in, const float* __restrict__ g,
+// IN16: the input rows are 16-bit (the GEMM epilogue that produced them rounded once more); else fp32.
+template <bool F16, bool HEAD, bool IN16 = false>
+__global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restrict__ in, const float* __restrict__ g,
                                                            const float* __restrict__ bt, float* __restrict__ out32,
                                                            h16* __restrict__ out16, int rows, HeadParams hp) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const float* src = in + (long long)row * 768;
   float v[12];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float4 x = *(const float4*)(src + i * 256 + lane * 4);
+    float4 x;
+    if constexpr (IN16) {
+      const u16x4 h = *(const u16x4*)((const h16*)in + (long long)row * 768 + i * 256 + lane * 4);
+      x = make_float4(from_h16<F16>(h[0]), from_h16<F16>(h[1]), from_h16<F16>(h[2]), from_h16<F16>(h[3]));
+    } else {
+      x = *(const float4*)((const float*)in + (long long)row * 768 + i * 256 + lane * 4);
+    }
     v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
     s += (x.x + x.y) + (x.z + x.w);
   }

@@ -96,6 +96,12 @@ __device__ __forceinline__ void epilogue_rows(const float* lds, const GemmParams
         v[k] += bv[k];
         if constexpr (EPI & EPI_GELU) v[k] = gelu_f(v[k]);
       }
+      if constexpr (EPI & EPI_RESID16) {
+        const int row_c = row < p.M ? row : p.M - 1;
+        const u16x8 rv = *(const u16x8*)((const h16*)p.resid + (long long)row_c * p.ldc + ccol_z + (col_ok ? col : 0));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += from_h16<F16>(rv[k]);
+      }
       if (row < p.M && col_ok) {
         const long long idx = (long long)row * p.ldc + ccol_z + col;
         *(uint4*)((h16*)p.C + idx) = make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]),

@@ -60,7 +60,9 @@ struct vtc_model {
 
   // workspace
   h16 *actA = nullptr, *actB = nullptr, *x16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffn16 = nullptr, *posin = nullptr;
-  float *h0 = nullptr, *tmp32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+  float *h0 = nullptr, *tmp32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr, *c0_xscale = nullptr;
+  _Float16* c0_aop = nullptr;   // conv0 MFMA operand (B, 512, 32), written per batch by the GroupNorm finalize kernel
+  int* c0_flag = nullptr;
   double* mom_partial = nullptr;
   int nchunk = 0;
 
@@ -82,6 +84,8 @@ struct vtc_model {
   bool big_tiles = true;   // 256x256 8-phase GEMM (VTC_GEMM_TILE=128 selects the 128x128 kernel, for A/B runs)
 
   bool prof_on = false;
+  bool conv0_mfma = true;  // conv0 as one fp16-split MFMA per 16 x 16 outputs (env VTC_CONV0_MFMA=0: VALU form)
+  bool pre_ln16 = false;   // pre-LayerNorm rows of the transformer layers in 16 bit (default: on for fp16; env VTC_PRE_LN16)
   std::vector<ProfRec> prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_next = 0;
@@ -230,11 +234,22 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   LAUNCH(m, PC_CONV0_STATS, 0.0, (double)nw * m->spec.window_samples * 4, s, {
     hipLaunchKernelGGL(conv0_moments_kernel, dim3(m->nchunk, nw), dim3(256), 0, s, wav, wt, L[0], m->mom_partial);
     hipLaunchKernelGGL(conv0_gn_finalize_kernel, dim3(nw), dim3(512), 0, s, m->mom_partial, m->nchunk, L[0], m->conv0_w,
-                       m->gn_w, m->gn_b, m->gn_scale, m->gn_shift);
+                       m->gn_w, m->gn_b, m->gn_scale, m->gn_shift, m->c0_aop, m->c0_xscale, m->c0_flag);
   });
-  LAUNCH(m, PC_CONV0_APPLY, 0.0, (double)nw * (m->spec.window_samples * 4.0 + (double)L[0] * 512 * 2), s,
-         hipLaunchKernelGGL((conv0_apply_kernel<F16>), dim3((L[0] + kC0Frames - 1) / kC0Frames, nw), dim3(256), 0, s, wav,
-                            wt, L[0], m->conv0_w, m->gn_scale, m->gn_shift, m->actA));
+  const double c0_bytes = (double)nw * (m->spec.window_samples * 4.0 + (double)L[0] * 512 * 2);
+  if (F16 && m->conv0_mfma) {   // fp16-split MFMA form; bf16 operands keep the VALU form
+    LAUNCH(m, PC_CONV0_APPLY, 0.0, c0_bytes, s,
+           {
+             hipLaunchKernelGGL(conv0_mfma_kernel, dim3((L[0] + kC0mFrames - 1) / kC0mFrames, nw), dim3(256), 0, s, wav, wt, L[0],
+                                m->c0_aop, m->c0_xscale, m->c0_flag, m->actA);
+             hipLaunchKernelGGL(conv0_valu_fallback_kernel, dim3(8, nw), dim3(256), 0, s, wav, wt, L[0], m->c0_flag, m->conv0_w,
+                                m->gn_scale, m->gn_shift, m->actA);
+           });
+  } else {
+    LAUNCH(m, PC_CONV0_APPLY, 0.0, c0_bytes, s,
+           hipLaunchKernelGGL((conv0_apply_kernel<F16>), dim3((L[0] + kC0Frames - 1) / kC0Frames, nw), dim3(256), 0, s, wav,
+                              wt, L[0], m->conv0_w, m->gn_scale, m->gn_shift, m->actA));
+  }
   if (m->debug_stop == 0) return 0;
 
   // ---- conv 1..6 as implicit GEMM over channel-last activations, GELU fused
@@ -266,7 +281,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
                             m->pos_w, m->pos_b, m->h0, m->tmp32, T));
   HeadParams nohead{};
   LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-         hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, m->enc_ln_w,
+         hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), dim3((M + 3) / 4), dim3(256), 0, s, (const void*)m->tmp32, m->enc_ln_w,
                             m->enc_ln_b, (float*)nullptr, m->x16, M, nohead));
   if (m->debug_stop == 8) return 0;
 
@@ -279,24 +294,36 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
     gemm_go<F16, 128, EPI_BIAS>(m, plain(m->x16, w.qkv_w, m->qkv16, w.qkv_b, nullptr, M, 2304, 768), 1, s);
     LAUNCH(m, PC_ATTN, attn_flops, 0.0, s,
            hipLaunchKernelGGL((attention_kernel<F16>), dim3(nqb, nw * 12), dim3(512), 0, s, m->qkv16, m->ctx16, T, nkt));
-    gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(m->ctx16, w.o_w, m->tmp32, w.o_b, (const float*)m->x16, M, 768, 768), 1, s);
-    LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-           hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln1_w,
-                              w.ln1_b, (float*)nullptr, m->x16, M, nohead));
-    gemm_go<F16, 128, EPI_BIAS | EPI_GELU>(m, plain(m->x16, w.ff1_w, m->ffn16, w.ff1_b, nullptr, M, 3072, 768), 1, s);
-    gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(m->ffn16, w.ff2_w, m->tmp32, w.ff2_b, (const float*)m->x16, M, 768, 3072), 1, s);
-    const bool last = l == VTC_N_LAYERS - 1;
-    if (!last || m->debug_stop == 9 + l) {
-      LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-             hipLaunchKernelGGL((layernorm768_kernel<F16, false>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
-                                w.ln2_b, (float*)nullptr, m->x16, M, nohead));
-    } else {
-      // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
+    // out-proj / FFN2 add the 16-bit residual in the epilogue and hand the pre-LayerNorm rows to LN768, either
+    // as fp32 (tmp32) or, with pre_ln16, rounded to 16 bit (half the store burst and half the LN read)
+    auto resid_gemm = [&](const h16* A, const h16* W, const float* b, int K) {
+      if (m->pre_ln16)
+        gemm_go<F16, 128, EPI_BIAS | EPI_RESID16>(m, plain(A, W, m->tmp32, b, (const float*)m->x16, M, 768, K), 1, s);
+      else
+        gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(A, W, m->tmp32, b, (const float*)m->x16, M, 768, K), 1, s);
+    };
+    auto ln768 = [&](const float* g, const float* b, bool head) {
+      const double bytes = (double)M * 768 * (m->pre_ln16 ? 4 : 6);
       HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
-      LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-             hipLaunchKernelGGL((layernorm768_kernel<F16, true>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, w.ln2_w,
-                                w.ln2_b, (float*)nullptr, m->x16, M, hp));
-    }
+      const dim3 grid((M + 3) / 4), blk(256);
+      if (head) {   // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
+        if (m->pre_ln16)
+          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, true, true>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, hp));
+        else
+          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, true, false>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, hp));
+      } else {
+        if (m->pre_ln16)
+          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, false, true>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, nohead));
+        else
+          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, nohead));
+      }
+    };
+    resid_gemm(m->ctx16, w.o_w, w.o_b, 768);
+    ln768(w.ln1_w, w.ln1_b, false);
+    gemm_go<F16, 128, EPI_BIAS | EPI_GELU>(m, plain(m->x16, w.ff1_w, m->ffn16, w.ff1_b, nullptr, M, 3072, 768), 1, s);
+    resid_gemm(m->ffn16, w.ff2_w, w.ff2_b, 3072);
+    const bool last = l == VTC_N_LAYERS - 1;
+    ln768(w.ln2_w, w.ln2_b, last && m->debug_stop != 9 + l);
     if (m->debug_stop == 9 + l) return 0;
   }
   return 0;
@@ -373,7 +400,10 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   m->spec = *spec;
   m->device = device;
   m->f16 = spec->mfma_dtype == 1;
+  m->pre_ln16 = m->f16;   // fp16 keeps 11 significand bits; bf16 rows stay fp32 ahead of LayerNorm
   if (const char* e = getenv("VTC_GEMM_TILE")) m->big_tiles = atoi(e) != 128;
+  if (const char* e = getenv("VTC_PRE_LN16")) m->pre_ln16 = atoi(e) != 0;
+  if (const char* e = getenv("VTC_CONV0_MFMA")) m->conv0_mfma = atoi(e) != 0;
   m->T = (int)T;
   {
     int n = spec->window_samples;
@@ -443,7 +473,10 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   TRY(dev_alloc(m, &m->gn_scale, B * 512));
   TRY(dev_alloc(m, &m->gn_shift, B * 512));
   m->nchunk = (m->L[0] + kStatChunk - 1) / kStatChunk;
-  TRY(dev_alloc(m, &m->mom_partial, B * m->nchunk * kStatN));
+  TRY(dev_alloc(m, &m->mom_partial, B * m->nchunk * kStatSlots));
+  TRY(dev_alloc(m, &m->c0_aop, B * 512 * 32));
+  TRY(dev_alloc(m, &m->c0_xscale, B));
+  TRY(dev_alloc(m, &m->c0_flag, B));
   TRY(dev_alloc(m, &m->d_start, B));
   TRY(dev_alloc(m, &m->d_dst, B));
   TRY(dev_alloc(m, &m->d_valid, B));
