@@ -1,5 +1,7 @@
 // Multi-head self-attention for one window (12 heads x 64), flash-style, K/V streamed through LDS.
-// Arithmetic: softmax(q k^T) v with q pre-scaled by 64^-0.5 (HF modeling_hubert.py:234-260, 318-341).
+// Arithmetic: softmax(q k^T) v with q pre-scaled by 64^-0.5 (HF modeling_hubert.py:234-260, 318-341).  The QKV
+// weights also carry log2(e), so the scores arrive in the log2 domain and the softmax is exp2(s - max): one
+// subtract and one v_exp_f32 per score.
 //
 // Layout choices (v_mfma_f32_32x32x16, C/D: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)):
 //   * S^T = K * Q^T, so the QUERY sits on the lane and a query's keys sit in the accumulator registers
@@ -17,6 +19,14 @@
 namespace vtc {
 
 constexpr int kAttnWaves = 8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 constexpr int kAttnStage = 16384;  // K tile 64 x 128 B, then V tile 64 x 128 B
 
 template <bool F16>
@@ -52,9 +62,8 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
     for (int s = 0; s < 4; ++s) qf[s] = *(const u16x8*)(qsrc + s * 16);
   }
 
-  f32x16 o0, o1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 o0 = kZero16, o1 = kZero16;
   float m = -1e30f, l = 0.f;
 
   // K fragment: row = u*32 + r, 16-B chunk (2*st + hh) ^ swz(row);  swz(row) = (row>>1)&7 is the same for u = 0,1
@@ -77,14 +86,17 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
 
     f32x16 s0, s1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-#pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int co = ((2 * st + hh) ^ k_sw) << 4;
       const u16x8 k0 = *(const u16x8*)(Ks + k_row_off + co);
       const u16x8 k1 = *(const u16x8*)(Ks + 32 * 128 + k_row_off + co);
-      s0 = mfma32<F16>(k0, qf[st], s0);
-      s1 = mfma32<F16>(k1, qf[st], s1);
+      if (st == 0) {   // zero accumulator as an inline constant: no 32 v_mov per tile
+        s0 = mfma32<F16>(k0, qf[0], kZero16);
+        s1 = mfma32<F16>(k1, qf[0], kZero16);
+      } else {
+        s0 = mfma32<F16>(k0, qf[st], s0);
+        s1 = mfma32<F16>(k1, qf[st], s1);
+      }
     }
     if (kt == nkt - 1) {
 #pragma unroll
@@ -94,43 +106,50 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
         if (key + 32 >= T) s1[i] = -1e30f;
       }
     }
-    float mx = fmaxf(s0[0], s1[0]);
+    // row maximum: v_max3 chain (the scores are MFMA results, never signalling NaNs: no canonicalising v_max needed)
+    float mx = max3f(s0[0], s0[1], s0[2]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+    for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+    mx = max3f(mx, s0[15], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 15; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+    mx = fmaxf(mx, s1[15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (__any(mx > m)) {   // some query of this wave raised its running maximum: rescale (exact)
       const float m_new = fmaxf(m, mx);
-      const float alpha = __expf(m - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
       m = m_new;
       l *= alpha;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
     }
-    float psum = 0.f;
+    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      s0[i] = __expf(s0[i] - m);
-      s1[i] = __expf(s1[i] - m);
-      psum += s0[i] + s1[i];
+      s0[i] = __builtin_amdgcn_exp2f(s0[i] - m);
+      s1[i] = __builtin_amdgcn_exp2f(s1[i] - m);
+      psum0 += s0[i];
+      psum1 += s1[i];
     }
-    l += psum;
+    l += psum0 + psum1;
 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        u16x8 pf;
+        u32x4 pw;   // the S^T accumulators, 16 bit, ARE the B operand: pairs (0,1) (2,3) (4,5) (6,7) of this 8-key slice
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = to_h16<F16>(u ? s1[8 * st + j] : s0[8 * st + j]);
+        for (int j = 0; j < 4; ++j)
+          pw[j] = u ? pack2<F16>(s1[8 * st + 2 * j], s1[8 * st + 2 * j + 1]) : pack2<F16>(s0[8 * st + 2 * j], s0[8 * st + 2 * j + 1]);
+        const u16x8 pf = __builtin_bit_cast(u16x8, pw);
         const char* va = Vs + (u * 32 + st * 16) * 128 + v_row_off;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int vc = v_col ^ (dt << 6);
           const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + vc));
           const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * 128 + vc));
-          u16x8 vf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { vf[j] = (unsigned short)v1[j]; vf[4 + j] = (unsigned short)v2[j]; }
+          const s16x8 vv = __builtin_shufflevector(v1, v2, 0, 1, 2, 3, 4, 5, 6, 7);
+          const u16x8 vf = __builtin_bit_cast(u16x8, vv);
           if (dt == 0) o0 = mfma32<F16>(vf, pf, o0);
           else         o1 = mfma32<F16>(vf, pf, o1);
         }

@@ -30,7 +30,16 @@ template <bool F16> __device__ __forceinline__ float from_h16(h16 v) {
   else               return __uint_as_float(((unsigned)v) << 16);
 }
 template <bool F16> __device__ __forceinline__ unsigned pack2(float a, float b) {
-  return (unsigned)to_h16<F16>(a) | ((unsigned)to_h16<F16>(b) << 16);
+  // vector conversions so that one v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 (round to nearest even) makes the pair
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  if constexpr (F16) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  } else {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  }
 }
 
 template <bool F16> __device__ __forceinline__ f32x4 mfma16(u16x8 a, u16x8 b, f32x4 c) {

@@ -32,6 +32,7 @@ struct GemmParams {
   long long w_z_stride;      // elements
   int c_col_z;
   int tiles_m, tiles_n;
+  int group_n;               // gemm256: tile columns per L2 group (divides tiles_n), see tile_coords()
 };
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }

@@ -57,6 +57,16 @@ struct Tile256 {
   static constexpr int SMEM = 2 * BUF;
 };
 
+// Tile order: columns are walked in groups of group_n; inside a group tile_n runs fastest, then tile_m.  With the
+// XCD remap (consecutive tiles share an XCD) the W panel of a group (group_n x BN x K, sized to stay in the 4 MiB
+// L2 by launch_gemm256) is fetched once per XCD instead of once per round, and the A rows once per group.
+__device__ __forceinline__ void tile_coords(const GemmParams& p, unsigned t, int& tile_m, int& tile_n) {
+  const unsigned per_group = (unsigned)(p.tiles_m * p.group_n);
+  const unsigned g = t / per_group, r = t - g * per_group;
+  tile_m = (int)(r / (unsigned)p.group_n);
+  tile_n = (int)(g * (unsigned)p.group_n + r % (unsigned)p.group_n);
+}
+
 template <bool F16, int EPI, int BN>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   using TC = Tile256<BN>;
@@ -200,8 +210,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const unsigned G = gridDim.x;
   unsigned tl = blockIdx.x;
   {
-    const unsigned t0 = xcd_remap(tl, ntiles);
-    set_sources((int)(t0 / (unsigned)p.tiles_n), (int)(t0 % (unsigned)p.tiles_n));
+    int tm0, tn0;
+    tile_coords(p, xcd_remap(tl, ntiles), tm0, tn0);
+    set_sources(tm0, tn0);
   }
   prologue();
 
@@ -255,8 +266,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   while (tl < ntiles) {
     const unsigned tcur = xcd_remap(tl, ntiles);
-    const int tile_n = (int)(tcur % (unsigned)p.tiles_n);
-    const int tile_m = (int)(tcur / (unsigned)p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(p, tcur, tile_m, tile_n);
 
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -285,8 +296,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       VTC_KTILE(1, true, t + 2, true, t + 3, )
     }
     VTC_KTILE(0, true, nk - 1, has_next, 0, if (has_next) {
-      const unsigned tn = xcd_remap(tl_next, ntiles);
-      set_sources((int)(tn / (unsigned)p.tiles_n), (int)(tn % (unsigned)p.tiles_n));
+      int tmn; int tnn;
+      tile_coords(p, xcd_remap(tl_next, ntiles), tmn, tnn);
+      set_sources(tmn, tnn);
     })
     VTC_KTILE(1, has_next, 0, has_next, 1, )
     if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -427,6 +439,16 @@ template <bool F16, int EPI, int BN>
 inline void launch_gemm256(GemmParams p, int nz, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / BN;
+  // largest divisor of tiles_n whose W panel (group_n x BN x K 16-bit) stays within ~2.5 MB of the XCD's 4 MiB L2
+  p.group_n = 1;
+  for (int g = 1; g <= p.tiles_n; ++g)
+    if (p.tiles_n % g == 0 && (long long)g * BN * p.K * 2 <= (5ll << 19)) p.group_n = g;
+#ifdef VTC_STAMPS
+  if (const char* e = getenv("VTC_GROUP_N")) {   // diagnostic override, only a positive divisor of tiles_n is taken
+    const int g = atoi(e);
+    if (g > 0 && p.tiles_n % g == 0) p.group_n = g;
+  }
+#endif
   const int ntiles = p.tiles_m * p.tiles_n;
   int cap = 256;
 #ifdef VTC_STAMPS

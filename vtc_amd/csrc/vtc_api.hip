@@ -436,14 +436,16 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
     LayerDev& d = m->layer[l];
     if (!s.q_w || !s.k_w || !s.v_w || !s.q_b || !s.k_b || !s.v_b || !s.o_w || !s.ff1_w || !s.ff2_w)
       return bail(fail(m, VTC_ERR_ARG, "missing weight in layer %d", l));
-    // fused QKV [2304][768]; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) is folded in (exact: 2^-3)
-    std::vector<unsigned short> qkv = pack_linear(s.q_w, 768, 768, f16, 0.125f, 768);
+    // fused QKV [2304][768]; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e) of the
+    // softmax's exp2 form (attention.cuh) are folded into the query rows
+    const float kQScale = 0.125f * 1.4426950408889634f;
+    std::vector<unsigned short> qkv = pack_linear(s.q_w, 768, 768, f16, kQScale, 768);
     std::vector<unsigned short> kk = pack_linear(s.k_w, 768, 768, f16), vv = pack_linear(s.v_w, 768, 768, f16);
     qkv.insert(qkv.end(), kk.begin(), kk.end());
     qkv.insert(qkv.end(), vv.begin(), vv.end());
     TRY(upload_h16(m, &d.qkv_w, qkv));
     std::vector<float> qb(2304);
-    for (int i = 0; i < 768; ++i) { qb[i] = s.q_b[i] * 0.125f; qb[768 + i] = s.k_b[i]; qb[1536 + i] = s.v_b[i]; }
+    for (int i = 0; i < 768; ++i) { qb[i] = s.q_b[i] * kQScale; qb[768 + i] = s.k_b[i]; qb[1536 + i] = s.v_b[i]; }
     TRY(upload_f32(m, &d.qkv_b, qb.data(), 2304));
     TRY(upload_h16(m, &d.o_w, pack_linear(s.o_w, 768, 768, f16)));
     TRY(upload_f32(m, &d.o_b, s.o_b, 768));
