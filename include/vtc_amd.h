@@ -42,7 +42,7 @@ typedef struct vtc_model vtc_model; /* opaque */
 typedef struct {
   int32_t abi_version;    /* VTC_ABI_VERSION */
   int32_t n_labels;       /* 1..VTC_MAX_LABELS */
-  int32_t window_samples; /* chunk_duration_s * 16000; 400 <= .. <= 164239 (T <= 512 frames) */
+  int32_t window_samples; /* chunk_duration_s * 16000; 400 <= .. <= 655759 (T <= 2048 frames) */
   int32_t max_batch;      /* windows per forward pass (segma's batch_size) */
   int32_t mfma_dtype;     /* 0 = bf16 operands, 1 = f16 operands (fp32 accumulate either way) */
   int32_t reserved[3];

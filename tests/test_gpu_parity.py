@@ -130,7 +130,7 @@ def _masks_and_segments(logits_cpu, uid="f"):
     return mask, O.intervals_to_segments(O.create_intervals(mask), uid)
 
 
-@pytest.mark.parametrize("chunk,seconds", [(4.0, 30.7), (10.0, 47.3)])
+@pytest.mark.parametrize("chunk,seconds", [(4.0, 30.7), (10.0, 47.3), (15.0, 36.2)])
 def test_file_logits_labels_and_segments(weights, chunk, seconds):
     """Multi-window file with a ragged tail: tiling, stitching, logits, labels, segments."""
     wav = synth.synth_audio(seconds, seed=11)

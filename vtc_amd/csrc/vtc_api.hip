@@ -384,8 +384,8 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   if (spec->max_batch < 1 || spec->max_batch > 4096) return fail(nullptr, VTC_ERR_ARG, "max_batch %d out of range", spec->max_batch);
   if (spec->mfma_dtype != 0 && spec->mfma_dtype != 1) return fail(nullptr, VTC_ERR_ARG, "mfma_dtype must be 0 (bf16) or 1 (f16)");
   const long long T = vtc_frames_for_samples(spec->window_samples);
-  if (T < 1 || T > 512)
-    return fail(nullptr, VTC_ERR_ARG, "window of %d samples gives %lld frames; supported 1..512",
+  if (T < 1 || T > 2048)   // attention streams K/V, nothing is sized by T but the scratch buffers; 2048 frames = 41 s
+    return fail(nullptr, VTC_ERR_ARG, "window of %d samples gives %lld frames; supported 1..2048",
                 spec->window_samples, T);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VTC_ERR_NO_GPU, "no HIP device visible");
