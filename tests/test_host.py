@@ -66,7 +66,7 @@ def test_bad_spec_rejected():
     h = ctypes.c_void_p()
     spec = lib.VtcSpec(abi_version=99, n_labels=4, window_samples=64000, max_batch=1, mfma_dtype=1)
     assert so.vtc_create(ctypes.byref(spec), ctypes.byref(lib.VtcWeights()), 0, ctypes.byref(h)) == lib.ERR_ARG
-    spec = lib.VtcSpec(abi_version=lib.ABI_VERSION, n_labels=4, window_samples=200000, max_batch=1, mfma_dtype=1)
+    spec = lib.VtcSpec(abi_version=lib.ABI_VERSION, n_labels=4, window_samples=700000, max_batch=1, mfma_dtype=1)
     assert so.vtc_create(ctypes.byref(spec), ctypes.byref(lib.VtcWeights()), 0, ctypes.byref(h)) == lib.ERR_ARG
     assert b"frames" in so.vtc_last_error(None)
 
