@@ -358,6 +358,48 @@ def test_cli_outputs_resume_and_error_rows(weights, tmp_path, monkeypatch):
     assert (tmp_path / "logs" / "benchmarks.jsonl").exists()
 
 
+def test_cli_durable_progress_and_resume_after_crash(tmp_path, monkeypatch):
+    """--flush_every: a run killed mid-shard keeps the flushed files, the rerun only does the rest, and the final parquet
+    files equal those of an uninterrupted run (reference writes once at the end, vtc.py:375-387)."""
+    from vtc_amd.audio import write_wav
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    uids = [f"g{i}" for i in range(6)]
+    for i, u in enumerate(uids):
+        write_wav(tmp_path / "audio" / f"{u}.wav", synth.synth_audio(1.5 + 0.7 * i, seed=70 + i))
+    listing = "path\n" + "\n".join(str(tmp_path / "audio" / f"{u}.wav") for u in uids) + "\n"
+    (tmp_path / "manifests" / "clean.csv").write_text(listing)
+    (tmp_path / "manifests" / "crash.csv").write_text(listing)
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    common = dict(config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=4, flush_seconds=0.0)
+    cli.main("clean", **common)
+
+    real, calls = cli.finish_file, {"n": 0}
+
+    def dying(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 5:
+            raise KeyboardInterrupt("simulated kill")
+        return real(*a, **k)
+
+    monkeypatch.setattr(cli, "finish_file", dying)
+    with pytest.raises(KeyboardInterrupt):
+        cli.main("crash", flush_every=2, **common)
+    monkeypatch.setattr(cli, "finish_file", real)
+    out = tmp_path / "output" / "crash"
+    flushed = pq.read_table(out / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()
+    assert flushed == uids[:4]                      # two flushes of two files each survived the kill
+    seen = []
+    monkeypatch.setattr(cli, "stage_audio", lambda path, dev, _f=cli.stage_audio: (seen.append(path), _f(path, dev))[1])
+    cli.main("crash", flush_every=2, **common)
+    assert [str(p).rsplit("/", 1)[-1] for p in seen] == ["g4.wav", "g5.wav"]   # only the unfinished files were redone
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        a = pq.read_table(tmp_path / "output" / "clean" / kind / "shard_0.parquet")
+        b = pq.read_table(out / kind / "shard_0.parquet")
+        assert a.schema.names == b.schema.names and a.to_pylist() == b.to_pylist(), kind
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)

@@ -139,7 +139,8 @@ def process_file(engine, wav: np.ndarray, uid: str, threshold: float, labels, ba
 def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
          threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 0,
          save_logits: bool = False, device: str = "cuda", array_id: int | None = None,
-         array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False):
+         array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False,
+         flush_every: int = 0, flush_seconds: float = 300.0):
     set_seeds(42)
     if device != "cuda":
         raise SystemExit(f"vtc_amd runs on ROCm GPUs only (--device {device} requested); it has no CPU path")
@@ -220,8 +221,48 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
 
     meta_rows, seg_rows = [], []
     n_errors, bytes_done, audio_seconds = 0, 0, 0.0
-    t0 = last_log = time.time()
+    t0 = last_log = last_flush = time.time()
+    since_flush = 0
     log_every = max(1, total // 20)
+    raw_path = paths.output / "vtc_raw" / f"shard_{shard_id}.parquet"
+    prev_seg_all = pq.read_table(raw_path).cast(SEGMENT_SCHEMA) if (raw_path.exists() and completed) else None
+
+    def write_outputs(final: bool):
+        """Shard outputs from the rows gathered so far, merged with the shard's previous rows (resume) and
+        de-duplicated; tmp + rename, so readers and a later resume never see a torn file.  Called at the end and,
+        for durable progress, every --flush_every files / --flush_seconds seconds (reference writes once, vtc.py:375-387)."""
+        new_meta = meta_table(meta_rows) if meta_rows else None
+        parts = []
+        if prev_meta is not None:
+            kept = _drop_uids(prev_meta, {r["uid"] for r in meta_rows}) if new_meta is not None else prev_meta
+            if kept.num_rows:
+                parts.append(kept.cast(new_meta.schema) if new_meta is not None else kept)
+        if new_meta is not None:
+            parts.append(new_meta)
+        meta_df = pa.concat_tables(parts) if parts else meta_table([])
+        before = meta_df.num_rows
+        meta_df = _unique_by_uid_keep_last(meta_df)
+        if final and meta_df.num_rows < before:
+            logger.warning(f"Dedup: removed {before - meta_df.num_rows} duplicate meta rows (shard {shard_id})")
+
+        new_seg = segments_table(seg_rows)
+        if prev_seg_all is not None:
+            prev_seg = _drop_uids(prev_seg_all, {r["uid"] for r in seg_rows})
+            seg_df = pa.concat_tables([t for t in (prev_seg, new_seg) if t.num_rows]) if (prev_seg.num_rows or new_seg.num_rows) else new_seg
+        else:
+            seg_df = new_seg
+        before = seg_df.num_rows
+        seg_df = _unique_rows(seg_df)
+        if final and seg_df.num_rows < before:
+            logger.warning(f"Dedup: removed {before - seg_df.num_rows} duplicate segment rows (shard {shard_id})")
+
+        # segments first, meta last: a uid only counts as done (resume) once its segments are on disk
+        atomic_write_parquet(seg_df, raw_path)
+        merged_df = merge_segments(seg_df, min_duration_off_s, min_duration_on_s)
+        atomic_write_parquet(merged_df, paths.output / "vtc_merged" / f"shard_{shard_id}.parquet")
+        atomic_write_parquet(meta_df, meta_path)
+        return seg_df, merged_df
+
     # Three overlapped stages: reader threads (decode + H2D on their own streams) -> one GPU thread (forward +
     # decode, in manifest order) -> this thread (segment rows, meta rows).  Per-file failures at any stage
     # become error rows and the run continues (reference vtc.py:245-249).
@@ -261,6 +302,11 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             meta_rows.append(row)
             bytes_done += sizes.get(uid, 0)
             now = time.time()
+            since_flush += 1
+            if i + 1 < total and ((flush_every > 0 and since_flush >= flush_every) or
+                                  (flush_seconds > 0 and now - last_flush >= flush_seconds)):
+                write_outputs(final=False)
+                since_flush, last_flush = 0, time.time()
             if (i + 1) % log_every == 0 or i + 1 == total or now - last_log >= 60:
                 rate = bytes_done / max(now - t0, 1e-9)
                 eta_s = (total_bytes - bytes_done) / rate if rate > 0 else 0
@@ -269,38 +315,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                       f" ({100.0 * bytes_done / total_bytes:.0f}%)  ETA {eta}", flush=True)
                 last_log = now
 
-    # ---- merge with the shard's previous rows (resume), de-duplicate
-    new_meta = meta_table(meta_rows) if meta_rows else None
-    parts = []
-    if prev_meta is not None:
-        kept = _drop_uids(prev_meta, {r["uid"] for r in meta_rows}) if new_meta is not None else prev_meta
-        if kept.num_rows:
-            parts.append(kept.cast(new_meta.schema) if new_meta is not None else kept)
-    if new_meta is not None:
-        parts.append(new_meta)
-    meta_df = pa.concat_tables(parts) if parts else meta_table([])
-    before = meta_df.num_rows
-    meta_df = _unique_by_uid_keep_last(meta_df)
-    if meta_df.num_rows < before:
-        logger.warning(f"Dedup: removed {before - meta_df.num_rows} duplicate meta rows (shard {shard_id})")
-
-    new_seg = segments_table(seg_rows)
-    raw_path = paths.output / "vtc_raw" / f"shard_{shard_id}.parquet"
-    if raw_path.exists() and completed:
-        prev_seg = _drop_uids(pq.read_table(raw_path).cast(SEGMENT_SCHEMA), {r["uid"] for r in seg_rows})
-        seg_df = pa.concat_tables([t for t in (prev_seg, new_seg) if t.num_rows]) if (prev_seg.num_rows or new_seg.num_rows) else new_seg
-    else:
-        seg_df = new_seg
-    before = seg_df.num_rows
-    seg_df = _unique_rows(seg_df)
-    if seg_df.num_rows < before:
-        logger.warning(f"Dedup: removed {before - seg_df.num_rows} duplicate segment rows (shard {shard_id})")
-
-    # ---- outputs (tmp + rename, zstd)
-    atomic_write_parquet(meta_df, meta_path)
-    atomic_write_parquet(seg_df, raw_path)
-    merged_df = merge_segments(seg_df, min_duration_off_s, min_duration_on_s)
-    atomic_write_parquet(merged_df, paths.output / "vtc_merged" / f"shard_{shard_id}.parquet")
+    seg_df, merged_df = write_outputs(final=True)
 
     wall = time.time() - t0
     print(flush=True)
@@ -337,6 +352,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--balance", action="store_true",
                    help="shard by file size (longest-processing-time) instead of equal counts; all workers of a run "
                         "must agree on this flag")
+    p.add_argument("--flush_every", type=int, default=0,
+                   help="also write the shard's parquet files after every N finished files (0 = only by time / at the end)")
+    p.add_argument("--flush_seconds", type=float, default=300.0,
+                   help="write the shard's parquet files at least this often while running (0 = only at the end); a crash "
+                        "then loses at most this much work and the resume rule picks up from the flushed files")
     add_sample_argument(p)
     return p
 
