@@ -106,6 +106,17 @@ int vtc_decode(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, co
                int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
                void* stream);
 
+/* Audio front-end of apply_model_on_audio (src/pipeline/vtc.py:236-243 decodes the file to mono 16 kHz float inside
+ * segma before the model runs): interleaved PCM already in device memory -> mono float32 at 16 kHz, on `stream`.
+ *   format 0 = int16 (scaled by 1/32768), 1 = float32; channels are averaged; sr_in != 16000 is resampled with the
+ *   windowed-sinc polyphase filter of torchaudio.functional.resample (sinc_interp_hann, width 6, rolloff 0.99), the
+ *   library the reference pulls in through segma (requirements.txt:393-394).  The rule itself is unpinned.
+ * *n_out = vtc_resampled_length(n_in, sr_in) = ceil(n_in * 16000 / sr_in); VTC_ERR_CAPACITY if out_cap is smaller.
+ * The per-rate filter table is built and kept in the handle on first use. */
+int64_t vtc_resampled_length(int64_t n_in, int32_t sr_in);
+int vtc_prepare_audio(vtc_model* m, const void* pcm /*[dev] n_in x n_channels, interleaved*/, int32_t format, int64_t n_in,
+                      int32_t n_channels, int32_t sr_in, float* out /*[dev]*/, int64_t out_cap, int64_t* n_out, void* stream);
+
 /* Test hook: copy an intermediate activation of the LAST vtc_forward_windows call to the host as fp32.
  * stage: 0..6 conv layer outputs (B,L_i,512); 7 projection (B*T,768); 8 encoder input after pos-conv+LN;
  * 9+l output of transformer layer l.  Returns the element count, or a negative status. */

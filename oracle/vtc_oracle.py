@@ -255,6 +255,49 @@ def apply_model_on_waveform(w: dict, wav: np.ndarray, chunk_duration_s: float, b
     return torch.cat(rows, dim=0)
 
 
+# ----------------------------------------------------------------------------- audio front-end (parity unpinned)
+def pcm_to_mono_float(pcm: np.ndarray) -> np.ndarray:
+    """int16 / float32 PCM, (n,) or (n, channels) -> float32 mono: int16 / 32768, channels averaged.
+    segma's rule is not in the reference: parity unpinned."""
+    x = np.asarray(pcm)
+    x = x.astype(np.float32) / np.float32(32768.0) if x.dtype == np.int16 else x.astype(np.float32)
+    if x.ndim == 2:
+        acc = np.zeros(x.shape[0], dtype=np.float32)
+        for c in range(x.shape[1]):
+            acc = acc + x[:, c]
+        x = acc / np.float32(x.shape[1]) if x.shape[1] > 1 else acc
+    return x
+
+
+def resample_sinc_hann(x: np.ndarray, sr_in: int, sr_out: int = SAMPLE_RATE) -> np.ndarray:
+    """torchaudio.functional.resample (the library segma pulls in, reference requirements.txt:393-394; absent here),
+    restated from its published algorithm: resampling_method="sinc_interp_hann", lowpass_filter_width=6, rolloff=0.99;
+    kernel built in float64 and cast to float32, applied as a strided conv1d, output trimmed to ceil(new*n/orig)."""
+    g = math.gcd(int(sr_in), int(sr_out))
+    orig, new = int(sr_in) // g, int(sr_out) // g
+    wav = torch.from_numpy(np.asarray(x, dtype=np.float32))
+    if orig == new:
+        return wav.numpy()
+    lowpass_filter_width, rolloff = 6, 0.99
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = t * base_freq
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels = (kernels * window * scale).to(torch.float32)                     # [new, 1, 2*width + orig]
+    length = wav.shape[0]
+    padded = F.pad(wav[None, None], (width, width + orig))
+    res = F.conv1d(padded, kernels, stride=orig)                               # [1, new, blocks]
+    res = res.transpose(1, 2).reshape(-1)
+    target = int(math.ceil(new * length / orig))
+    return res[:target].contiguous().numpy()
+
+
 # --------------------------------------------------------------------------- decode
 def apply_thresholds(logits: torch.Tensor, thresholds: dict, labels=DEFAULT_LABELS) -> torch.Tensor:
     """sigmoid(logit) within [lower_bound, upper_bound] per label (call site vtc.py:84-90).

@@ -391,13 +391,64 @@ def test_cli_durable_progress_and_resume_after_crash(tmp_path, monkeypatch):
     flushed = pq.read_table(out / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()
     assert flushed == uids[:4]                      # two flushes of two files each survived the kill
     seen = []
-    monkeypatch.setattr(cli, "stage_audio", lambda path, dev, _f=cli.stage_audio: (seen.append(path), _f(path, dev))[1])
+    monkeypatch.setattr(cli, "stage_audio", lambda path, eng, _f=cli.stage_audio: (seen.append(path), _f(path, eng))[1])
     cli.main("crash", flush_every=2, **common)
     assert [str(p).rsplit("/", 1)[-1] for p in seen] == ["g4.wav", "g5.wav"]   # only the unfinished files were redone
     for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
         a = pq.read_table(tmp_path / "output" / "clean" / kind / "shard_0.parquet")
         b = pq.read_table(out / kind / "shard_0.parquet")
         assert a.schema.names == b.schema.names and a.to_pylist() == b.to_pylist(), kind
+
+
+# ----------------------------------------------------------------------------- audio front-end
+@pytest.mark.parametrize("sr,ch,dtype", [(16000, 1, "int16"), (16000, 2, "int16"), (44100, 2, "int16"), (48000, 1, "float32"),
+                                         (8000, 1, "int16"), (22050, 3, "float32"), (32000, 1, "int16")])
+def test_gpu_front_end_against_oracle(weights, sr, ch, dtype):
+    """vtc_prepare_audio (channel mix + windowed-sinc resampling on the GPU) against the oracle's restatement of
+    torchaudio.functional.resample and against the host route (audio.sinc_resample).  int16 -> float and the mono mix
+    are exact; the filter is an fp32 sum of <= ~40 products, compared at 2e-6.  Parity with segma itself: unpinned."""
+    from vtc_amd import audio
+    rng = np.random.default_rng(sr + ch)
+    n = int(1.37 * sr) + 13
+    x = rng.standard_normal((n, ch)) * 0.2
+    pcm = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16) if dtype == "int16" else x.astype(np.float32)
+    if ch == 1:
+        pcm = pcm[:, 0].copy()
+    mono = O.pcm_to_mono_float(pcm)
+    ref = O.resample_sinc_hann(mono, sr)
+    eng = _engine(weights, 1.0, 2)
+    got = eng.prepare_audio(torch.from_numpy(pcm).cuda(), sr).cpu().numpy()
+    assert got.shape == ref.shape == (-(-16000 * n // sr),)
+    if sr == 16000:
+        assert np.array_equal(got, mono)                       # conversion and mix: bit exact
+    else:
+        assert np.abs(got - ref).max() <= 2e-6
+        assert np.abs(got - audio.sinc_resample(mono, sr)).max() <= 2e-6
+    eng.close()
+
+
+def test_cli_accepts_stereo_44k_file(weights, tmp_path, monkeypatch):
+    """A 44.1 kHz stereo WAV goes through the CLI (GPU front-end) and gives the logits of the oracle run on the
+    oracle-resampled mono signal."""
+    from scipy.io import wavfile
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    base = synth.synth_audio(6.0, seed=91)
+    up = np.interp(np.arange(int(6.0 * 44100)) / 44100.0, np.arange(len(base)) / 16000.0, base).astype(np.float32)
+    stereo = np.stack([up, 0.5 * up[::-1]], axis=1)
+    pcm = np.clip(np.round(stereo * 32768), -32768, 32767).astype(np.int16)
+    wavfile.write(tmp_path / "audio" / "s44.wav", 44100, pcm)
+    (tmp_path / "manifests" / "hi.csv").write_text(f"path\n{tmp_path / 'audio' / 's44.wav'}\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    cli.main("hi", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=4, save_logits=True)
+    saved = torch.load(tmp_path / "output" / "hi" / "logits" / "s44-logits_dict_t.pt", weights_only=True)
+    got = torch.stack([saved[l] for l in O.DEFAULT_LABELS], dim=1)
+    ref = O.apply_model_on_waveform(weights, O.resample_sinc_hann(O.pcm_to_mono_float(pcm), 44100), 4.0)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= LOGIT_TOL
+    meta = pq.read_table(tmp_path / "output" / "hi" / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert meta[0]["uid"] == "s44" and meta[0]["error"] == ""
 
 
 def pa_buf(b):

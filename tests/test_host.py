@@ -311,3 +311,19 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert outs[0]["mine"] + outs[1]["mine"] == [f"f{i}" for i in range(11)]
     assert not set(outs[0]["mine"]) & set(outs[1]["mine"])
     assert all(o["slowest"] == 2.0 and o["total"] == 11 for o in outs)
+
+
+def test_host_resampler_matches_oracle_restatement_of_torchaudio():
+    """audio.sinc_resample (host form of the GPU front-end) vs oracle.resample_sinc_hann (torchaudio's published
+    algorithm restated with torch ops); lengths are ceil(n * 16000 / sr)."""
+    from vtc_amd import audio
+    rng = np.random.default_rng(3)
+    for sr in (8000, 11025, 22050, 32000, 44100, 48000, 96000):
+        x = (rng.standard_normal(sr // 3 + 29) * 0.1).astype(np.float32)
+        a, b = O.resample_sinc_hann(x, sr), audio.sinc_resample(x, sr)
+        assert a.shape == b.shape == (-(-16000 * len(x) // sr),)
+        assert np.abs(a - b).max() <= 1e-6, sr
+    t = np.arange(48000) / 48000.0
+    y = audio.sinc_resample(np.sin(2 * np.pi * 440 * t).astype(np.float32), 48000)
+    assert np.abs(y[200:-200] - np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000.0)[200:-200]).max() < 1e-3
+    assert np.array_equal(audio.sinc_resample(np.ones(5, np.float32), 16000), np.ones(5, np.float32))

@@ -2,7 +2,11 @@
 
 The reference leaves decoding to segma (torchaudio/torchcodec, requirements.txt:393-394); the rule for
 non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float)
-through scipy with mmap; channels are averaged; other rates are resampled with a polyphase filter.
+through scipy with mmap; channels are averaged; other rates are resampled with torchaudio's windowed-sinc
+polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
+
+Two routes give the same samples: `read_pcm` + `VtcEngine.prepare_audio` (raw PCM is copied to the GPU and
+mixed / resampled there: the pipeline's route) and `read_audio` (all on the host: tests, small tools).
 """
 
 from __future__ import annotations
@@ -29,6 +33,57 @@ def to_float32(data: np.ndarray) -> np.ndarray:
     return out
 
 
+def read_pcm(path):
+    """Decode only as far as the container: (samples, sample_rate) with samples int16 or float32, shape (n,) or
+    (n, channels), memory-mapped when the format allows.  Mixing and resampling are left to the GPU."""
+    from scipy.io import wavfile
+
+    path = Path(path)
+    if path.suffix.lower() not in (".wav", ".wave"):
+        raise ValueError(f"{path.name}: only WAV input is supported by this build (got '{path.suffix}')")
+    try:
+        sr, data = wavfile.read(str(path), mmap=True)
+    except ValueError:
+        sr, data = wavfile.read(str(path), mmap=False)   # 24-bit PCM cannot be memory-mapped
+    if data.dtype not in (np.int16, np.float32):
+        data = to_float32(np.asarray(data))
+    return data, int(sr)
+
+
+def sinc_resample_kernel(sr_in: int, sr_out: int = SAMPLE_RATE):
+    """torchaudio.functional.resample's filter (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99):
+    (orig, new, width, kernels float32 [new, 2*width+orig]), computed in float64."""
+    g = gcd(int(sr_in), int(sr_out))
+    orig, new = int(sr_in) // g, int(sr_out) // g
+    lpw, rolloff = 6.0, 0.99
+    base_freq = min(orig, new) * rolloff
+    width = int(np.ceil(lpw * orig / base_freq))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base_freq
+    t = np.clip(t, -lpw, lpw)
+    window = np.cos(t * np.pi / lpw / 2.0) ** 2
+    t = t * np.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        k = np.where(t == 0.0, 1.0, np.sin(t) / t) * window * (base_freq / orig)
+    return orig, new, width, k.astype(np.float32)
+
+
+def sinc_resample(x: np.ndarray, sr_in: int) -> np.ndarray:
+    """Host form of the GPU resampler (vtc_prepare_audio): float32 mono at sr_in -> 16 kHz."""
+    orig, new, width, k = sinc_resample_kernel(sr_in)
+    x = np.asarray(x, dtype=np.float32)
+    if orig == new:
+        return x
+    n = x.shape[0]
+    n_out = -(-new * n // orig)
+    blocks = n // orig + 1
+    pad = np.zeros(width + blocks * orig + width + orig, dtype=np.float32)
+    pad[width:width + n] = x
+    win = np.lib.stride_tricks.sliding_window_view(pad, k.shape[1])[::orig][:blocks]      # [blocks, K]
+    out = (win.astype(np.float32) @ k.T.astype(np.float32)).reshape(-1)                   # block-major, phase-minor
+    return np.ascontiguousarray(out[:n_out], dtype=np.float32)
+
+
 def read_audio(path) -> np.ndarray:
     """Decode one file to mono 16 kHz float32.  Raises on anything unreadable; the host turns the
     exception into an error row (reference src/pipeline/vtc.py:245-249)."""
@@ -45,9 +100,7 @@ def read_audio(path) -> np.ndarray:
     if x.ndim == 2:
         x = x.mean(axis=1, dtype=np.float32)
     if sr != SAMPLE_RATE:
-        from scipy.signal import resample_poly
-        g = gcd(SAMPLE_RATE, int(sr))
-        x = resample_poly(x, SAMPLE_RATE // g, int(sr) // g).astype(np.float32)
+        x = sinc_resample(x, int(sr))
     return np.ascontiguousarray(x, dtype=np.float32)
 
 

@@ -7,11 +7,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/vtc_amd.h"
 #include "attention.cuh"
+#include "audio_kernels.cuh"
 #include "common.cuh"
 #include "decode_kernels.cuh"
 #include "encoder_kernels.cuh"
@@ -83,6 +85,8 @@ struct vtc_model {
   int debug_stop = -1;
   bool big_tiles = true;   // 256x256 8-phase GEMM (VTC_GEMM_TILE=128 selects the 128x128 kernel, for A/B runs)
 
+  struct ResampleDev { ResampleTable t; };
+  std::map<int, ResampleDev> resample;   // per input sample rate, built on first use (vtc_prepare_audio)
   bool prof_on = false;
   bool conv0_mfma = true;  // conv0 as one fp16-split MFMA per 16 x 16 outputs (env VTC_CONV0_MFMA=0: VALU form)
   bool pre_ln16 = false;   // pre-LayerNorm rows of the transformer layers in 16 bit (default: on for fp16; env VTC_PRE_LN16)
@@ -637,6 +641,97 @@ int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t nw, float* out, int
     else { unsigned u = (unsigned)tmp[i] << 16; memcpy(&out[i], &u, 4); }
   }
   return n;
+}
+
+int64_t vtc_resampled_length(int64_t n_in, int32_t sr_in) {
+  if (n_in < 0 || sr_in <= 0) return -1;
+  long long a = sr_in, b = 16000;
+  while (b) { const long long t = a % b; a = b; b = t; }
+  const long long orig = sr_in / a, nw = 16000 / a;
+  return (nw * n_in + orig - 1) / orig;   // ceil(new * n / orig), torchaudio's target_length
+}
+
+// torchaudio.functional.resample's kernel (_get_sinc_resample_kernel, sinc_interp_hann, width 6, rolloff 0.99), fp64 -> fp32,
+// stored compactly: per phase only the taps inside the window's support (|w| >= 1e-30; the clamped taps outside are ~1e-34).
+static int build_resample(vtc_model* m, int sr_in, ResampleTable* out) {
+  auto it = m->resample.find(sr_in);
+  if (it != m->resample.end()) { *out = it->second.t; return VTC_OK; }
+  long long a = sr_in, b = 16000;
+  while (b) { const long long t = a % b; a = b; b = t; }
+  const int orig = (int)(sr_in / a), nw = (int)(16000 / a);
+  ResampleTable t{};
+  t.orig = orig; t.new_ = nw;
+  if (orig != nw) {
+    const double lpw = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
+    const double base_freq = (double)(orig < nw ? orig : nw) * rolloff;
+    const int width = (int)std::ceil(lpw * orig / base_freq);
+    const int K = 2 * width + orig;
+    const double scale = base_freq / orig;
+    std::vector<int> first(nw), count(nw);
+    std::vector<std::vector<float>> rows(nw);
+    int kc = 1;
+    std::vector<float> full(K);
+    for (int p = 0; p < nw; ++p) {
+      int lo = K, hi = -1;
+      for (int k = 0; k < K; ++k) {
+        double tt = (-(double)p / nw + (double)(k - width) / orig) * base_freq;
+        tt = tt < -lpw ? -lpw : (tt > lpw ? lpw : tt);
+        const double c = std::cos(tt * pi / lpw / 2.0);
+        const double window = c * c;
+        tt *= pi;
+        const double kern = (tt == 0.0 ? 1.0 : std::sin(tt) / tt) * window * scale;
+        full[k] = (float)kern;
+        if (std::fabs(full[k]) >= 1e-30f) { if (k < lo) lo = k; hi = k; }
+      }
+      if (hi < lo) { lo = 0; hi = 0; }
+      first[p] = lo; count[p] = hi - lo + 1;
+      rows[p].assign(full.begin() + lo, full.begin() + hi + 1);
+      if (count[p] > kc) kc = count[p];
+    }
+    std::vector<float> w((size_t)nw * kc, 0.f);
+    for (int p = 0; p < nw; ++p) memcpy(&w[(size_t)p * kc], rows[p].data(), rows[p].size() * sizeof(float));
+    float* dw = nullptr; int* df = nullptr;
+    HIP_TRY(m, hipMalloc((void**)&dw, w.size() * sizeof(float)));
+    m->allocs.push_back(dw);
+    HIP_TRY(m, hipMalloc((void**)&df, first.size() * sizeof(int)));
+    m->allocs.push_back(df);
+    HIP_TRY(m, hipMemcpy(dw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(m, hipMemcpy(df, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+    t.width = width; t.kc = kc; t.w = dw; t.first = df;
+  }
+  m->resample[sr_in] = vtc_model::ResampleDev{t};
+  *out = t;
+  return VTC_OK;
+}
+
+int vtc_prepare_audio(vtc_model* m, const void* pcm, int32_t format, int64_t n_in, int32_t n_channels, int32_t sr_in,
+                      float* out, int64_t out_cap, int64_t* n_out, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!pcm || !out || !n_out) return fail(m, VTC_ERR_ARG, "null argument");
+  if (format != 0 && format != 1) return fail(m, VTC_ERR_ARG, "format must be 0 (int16) or 1 (float32)");
+  if (n_channels < 1 || n_channels > 64) return fail(m, VTC_ERR_ARG, "n_channels %d out of range 1..64", n_channels);
+  if (sr_in < 1000 || sr_in > 768000) return fail(m, VTC_ERR_ARG, "sample rate %d out of range 1000..768000", sr_in);
+  if (n_in < 0) return fail(m, VTC_ERR_ARG, "negative length");
+  const int64_t need = vtc_resampled_length(n_in, sr_in);
+  *n_out = need;
+  if (need > out_cap) return fail(m, VTC_ERR_CAPACITY, "output needs %lld samples, capacity %lld", (long long)need, (long long)out_cap);
+  if (need == 0) return VTC_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  ResampleTable t{};
+  const int rc = build_resample(m, sr_in, &t);
+  if (rc != VTC_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const long long blocks = (need + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(m, VTC_ERR_ARG, "input too long");
+  const double bytes = (double)n_in * n_channels * (format == 0 ? 2 : 4) + (double)need * 4;
+  if (format == 0)
+    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
+                                                         (long long)n_in, n_channels, t, out, (long long)need));
+  else
+    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
+                                                         (long long)n_in, n_channels, t, out, (long long)need));
+  HIP_TRY(m, hipGetLastError());
+  return VTC_OK;
 }
 
 int vtc_profile_enable(vtc_model* m, int32_t on) {

@@ -35,7 +35,7 @@ import pyarrow.compute as pc
 import pyarrow.parquet as pq
 import torch
 
-from ..audio import read_audio
+from ..audio import read_pcm
 from ..core.intervals import intervals_to_segments
 from ..core.metadata import vtc_error_row, vtc_meta_row
 from ..engine import RF_SIZE
@@ -87,22 +87,23 @@ def _unique_by_uid_keep_last(table: pa.Table) -> pa.Table:
     return table.take(pa.array(sorted(last.values())))
 
 
-def stage_audio(path, device: torch.device) -> torch.Tensor:
-    """Reader-thread stage: decode one file and put it in HBM on this thread's own copy stream, so that the
-    H2D transfer of file i+1 overlaps the forward of file i.  Returns only after the copy has landed."""
-    wav = read_audio(path)
-    if wav.shape[0] < RF_SIZE:
-        raise ValueError(f"audio too short: {wav.shape[0]} samples < receptive field {RF_SIZE}")
-    host = torch.from_numpy(wav)
-    if host.numel() < (1 << 20):
-        return host.to(device)
+def stage_audio(path, engine) -> torch.Tensor:
+    """Reader-thread stage: read the file's raw PCM (int16 / float32, any channel count and rate), copy it to HBM on this
+    thread's own stream and run the GPU front-end there (channel mix, resample to 16 kHz, float32), so that decode,
+    H2D and front-end of file i+1 overlap the forward of file i.  Returns only after the waveform is ready."""
+    pcm, sr = read_pcm(path)
+    device = engine.device
     copy_stream = getattr(_TLS, "stream", None)
     if copy_stream is None:
         copy_stream = _TLS.stream = torch.cuda.Stream(device)
+    host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=pcm.size >= (1 << 18))
+    np.copyto(host.numpy(), pcm)                      # page cache / mmap -> pinned staging, no conversion on the host
     with torch.cuda.stream(copy_stream):
-        gpu = host.pin_memory().to(device, non_blocking=True)
+        wav = engine.prepare_audio(host.to(device, non_blocking=True), sr)
     copy_stream.synchronize()
-    return gpu
+    if wav.numel() < RF_SIZE:
+        raise ValueError(f"audio too short: {wav.numel()} samples < receptive field {RF_SIZE}")
+    return wav
 
 
 def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logits: bool):
@@ -281,7 +282,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         def top_up():
             nonlocal nxt
             while nxt < total and len(pending) < depth + 1:
-                audio = readers.submit(stage_audio, uid_to_path[todo[nxt]], engine.device)
+                audio = readers.submit(stage_audio, uid_to_path[todo[nxt]], engine)
                 pending[nxt] = gpu_thread.submit(gpu_job, audio)
                 nxt += 1
 

@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from ..audio import read_audio
+from ..audio import read_pcm
 from ..engine import RF_SIZE
 
 _LAST_ENGINE = None   # engine of the most recent apply_model_on_audio call (create_intervals runs on it)
@@ -26,16 +26,16 @@ def apply_model_on_audio(audio_path, model, conv_settings=None, device="cuda", b
     g <-> sample g*320; reference src/analysis/chunk_artifact.py:60-83).  Raises on unreadable or too
     short audio; the reference host converts that into an error row (vtc.py:245-249)."""
     global _LAST_ENGINE
-    wav = read_audio(Path(audio_path))
-    if wav.shape[0] < RF_SIZE:
-        raise ValueError(f"audio too short: {wav.shape[0]} samples < receptive field {RF_SIZE}")
+    pcm, sr = read_pcm(Path(audio_path))
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     eng = model.engine(chunk_duration_s, batch_size, dev)
     _LAST_ENGINE = eng
-    host = torch.from_numpy(wav)
-    gpu = host.pin_memory().to(eng.device, non_blocking=True) if host.numel() >= (1 << 20) else host.to(eng.device)
+    host = torch.from_numpy(np.ascontiguousarray(pcm))
+    gpu = eng.prepare_audio(host.pin_memory().to(eng.device, non_blocking=True) if host.numel() >= (1 << 20) else host.to(eng.device), sr)
+    if gpu.numel() < RF_SIZE:
+        raise ValueError(f"audio too short: {gpu.numel()} samples < receptive field {RF_SIZE}")
     return eng.infer_waveform(gpu, batch_size)
 
 
