@@ -106,6 +106,23 @@ int vtc_decode(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, co
                int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
                void* stream);
 
+/* Several recordings in one call (second caller of the boundary: src/analysis/vtc_on_clips.py:154-211 runs
+ * apply_model_on_audio once per packaged clip, most of them shorter than a batch of windows).  Recording f is
+ * wav[offset[f] .. offset[f] + n_samples[f]) of one device arena; windows are planned per recording exactly as in
+ * vtc_infer_waveform and windows of different recordings share forward passes.  Stitched logits of recording f land
+ * in rows [file_rows[f], file_rows[f+1]) (file_rows has n_files + 1 entries, written by the call; a recording
+ * shorter than the receptive field gets zero rows).  Row results are bit-identical to per-recording calls. */
+int vtc_infer_waveforms(vtc_model* m, const float* wav /*[dev]*/, const int64_t* offset /*[host]*/,
+                        const int64_t* n_samples /*[host]*/, int32_t n_files, int32_t batch, float* logits /*[dev]*/,
+                        int64_t* file_rows /*[host] n_files+1, out*/, void* stream);
+/* vtc_decode over such a row layout: runs never cross a recording boundary, out_start / out_end are samples relative
+ * to the recording, output is recording-major and inside a recording label-major, time-ordered (= vtc_decode on each
+ * recording's rows).  No sigmoid summary.  Synchronises `stream`. */
+int vtc_decode_files(vtc_model* m, const float* logits /*[dev]*/, const int64_t* file_rows /*[host] n_files+1*/,
+                     int32_t n_files, const float* lo_logit /*[host]*/, const float* hi_logit /*[host]*/,
+                     int32_t* out_file /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,
+                     int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, void* stream);
+
 /* Audio front-end of apply_model_on_audio (src/pipeline/vtc.py:236-243 decodes the file to mono 16 kHz float inside
  * segma before the model runs): interleaved PCM already in device memory -> mono float32 at 16 kHz, on `stream`.
  *   format 0 = int16 (scaled by 1/32768), 1 = float32; channels are averaged; sr_in != 16000 is resampled with the

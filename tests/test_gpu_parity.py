@@ -451,6 +451,103 @@ def test_cli_accepts_stereo_44k_file(weights, tmp_path, monkeypatch):
     assert meta[0]["uid"] == "s44" and meta[0]["error"] == ""
 
 
+# ----------------------------------------------------------------------------- several recordings per call (clips)
+def test_multi_recording_batch_equals_per_recording(weights):
+    """vtc_infer_waveforms / vtc_decode_files: windows of many short recordings share forward passes; rows and decoded
+    runs must equal the per-recording calls bit for bit (windows are independent), and runs must not cross recordings."""
+    eng = _engine(weights, 4.0, 8)
+    secs = [0.02, 1.0, 3.99, 4.0, 4.03, 9.7, 0.5, 13.2, 2.2]          # first one is shorter than the receptive field
+    wavs = [torch.from_numpy(synth.synth_audio(d, seed=200 + i)).cuda() for i, d in enumerate(secs)]
+    logits, rows = eng.infer_waveforms(wavs, batch_size=8)
+    assert rows[0] == 0 and rows[1] == 0                               # too short: zero rows, no error
+    assert [int(rows[i + 1] - rows[i]) for i in range(len(secs))] == [O.n_frames_for_samples(int(w.numel())) for w in wavs]
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    fidx, s, e, lab = eng.decode_files(logits.contiguous(), rows, lo, hi)
+    assert list(fidx) == sorted(fidx)
+    for i, w in enumerate(wavs):
+        mine = logits[int(rows[i]):int(rows[i + 1])]
+        if i == 0:
+            assert mine.shape[0] == 0
+            continue
+        single = eng.infer_waveform(w, batch_size=8)
+        assert torch.equal(mine, single), i
+        ss, se, sl, _, _ = eng.decode(single.contiguous(), lo, hi)
+        sel = fidx == i
+        assert list(s[sel]) == list(ss) and list(e[sel]) == list(se) and list(lab[sel]) == list(sl), i
+        ref = O.apply_model_on_waveform(weights, w.cpu().numpy(), 4.0)
+        assert (mine.cpu() - ref).abs().max().item() <= LOGIT_TOL
+    # a boundary inside an active run splits it: all-active logits, two recordings of 5 and 7 frames
+    hot = torch.full((12, 4), 5.0, device="cuda")
+    f2, s2, e2, l2 = eng.decode_files(hot, np.array([0, 5, 12]), lo, hi)
+    assert list(f2) == [0] * 4 + [1] * 4 and list(s2) == [0] * 8
+    assert list(e2) == [4 * 320 + 400] * 4 + [6 * 320 + 400] * 4 and list(l2) == [0, 1, 2, 3] * 2
+    eng.close()
+
+
+def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
+    """vtc_amd.analysis.vtc_on_clips (reference src/analysis/vtc_on_clips.py): WebDataset tars in, clip-relative
+    segments out, resume by clip_id, per-clip errors counted and skipped."""
+    import io, tarfile
+    from scipy.io import wavfile
+    from vtc_amd.analysis import vtc_on_clips as clips
+    monkeypatch.chdir(tmp_path)
+    shard_dir = tmp_path / "output" / "ds" / "shards"
+    shard_dir.mkdir(parents=True)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "manifests" / "ds.csv").write_text("path\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    audio = {}
+
+    def add(tf, name, data):
+        info = tarfile.TarInfo(name)
+        info.size = len(data)
+        tf.addfile(info, io.BytesIO(data))
+
+    def wav_bytes(x, sr=16000):
+        buf = io.BytesIO()
+        wavfile.write(buf, sr, np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16))
+        return buf.getvalue()
+
+    k = 0
+    for t in range(2):
+        with tarfile.open(shard_dir / f"shards-{t:04d}.tar", "w") as tf:
+            for c in range(5):
+                cid = f"uidA_{k:04d}"
+                x = synth.synth_audio(2.0 + 1.7 * c, seed=300 + k)
+                audio[cid] = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+                add(tf, f"{cid}.wav", wav_bytes(x))
+                add(tf, f"{cid}.json", b"{}")
+                k += 1
+            if t == 0:
+                add(tf, "uidB_0000.flac", b"fLaC not decodable here")      # error, skipped
+                add(tf, "uidB_0001.json", b"{}")                            # no audio, error
+    common = dict(config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8)
+    clips.main("ds", **common)
+    out = tmp_path / "output" / "ds" / "vtc_clips"
+    raw = pq.read_table(out / "vtc_raw" / "shard_0.parquet")
+    assert raw.schema.names == ["clip_id", "onset", "offset", "duration", "label"]
+    rows = raw.to_pylist()
+    assert {r["clip_id"] for r in rows} <= set(audio)
+    for cid, pcm in audio.items():
+        ref = O.apply_model_on_waveform(weights, O.pcm_to_mono_float(pcm), 4.0)
+        if not (ref.abs() > LOGIT_TOL).all():
+            continue
+        want = O.intervals_to_segments(O.create_intervals(O.apply_thresholds(ref, THR)), cid)
+        mine = [dict(uid=r["clip_id"], onset=r["onset"], offset=r["offset"], duration=r["duration"], label=r["label"])
+                for r in rows if r["clip_id"] == cid]
+        key = lambda r: (r["label"], r["onset"])
+        assert sorted(mine, key=key) == sorted(want, key=key), cid
+    merged = pq.read_table(out / "vtc_merged" / "shard_0.parquet")
+    assert merged.schema.names == raw.schema.names and merged.num_rows <= raw.num_rows
+    # resume: nothing with segments is recomputed
+    calls = []
+    monkeypatch.setattr(clips, "run_group", lambda eng, group, *a, _f=clips.run_group: (calls.append([c for c, _ in group]), _f(eng, group, *a))[1])
+    clips.main("ds", **common)
+    done = {r["clip_id"] for r in rows}
+    assert all(c not in done for g in calls for c in g)
+    assert pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist() == rows
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""VTC on packaged clips, MI355X-native.  CLI-compatible with the reference's
+`python -m src.analysis.vtc_on_clips` (/root/reference/src/analysis/vtc_on_clips.py:74-338): for every clip in
+output/{dataset}/shards/*.tar (WebDataset layout, members `{clip_id}.{wav|flac}` + side files) it writes
+
+    output/{dataset}/vtc_clips/vtc_raw/shard_{id}.parquet      clip_id, onset, offset, duration, label
+    output/{dataset}/vtc_clips/vtc_merged/shard_{id}.parquet   same columns after the collar merge
+
+with onsets/offsets relative to the clip, the same resume rule (a clip_id present in ANY vtc_raw/shard_*.parquet is
+skipped, :119-125) and the same per-clip error behaviour (log, count, continue, :204-207).
+
+What differs is where the work runs: clips are decoded from the tar in memory (the reference writes each one to a
+temporary file, :177-184), their PCM goes to the GPU front-end, and clips are *batched together*: most clips are a
+few windows long, so windows of many clips share one forward pass (vtc_infer_waveforms) and one segmented
+threshold/run-length decode (vtc_decode_files) instead of one small launch chain per clip.
+
+Usage:
+    python -m vtc_amd.analysis.vtc_on_clips seedlings_10 --checkpoint VTC-2.0/model/best.ckpt
+"""
+
+from __future__ import annotations
+
+import argparse
+import io
+import logging
+import sys
+import tarfile
+import time
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pyarrow.parquet as pq
+import torch
+
+from ..audio import to_float32
+from ..core.intervals import intervals_to_segments
+from ..engine import RF_SIZE
+from ..segma_compat.config import load_config
+from ..segma_compat.config.base import Config
+from ..segma_compat.inference import logit_bounds
+from ..segma_compat.models import Models
+from ..segma_compat.utils.encoders import MultiLabelEncoder
+from ..utils import atomic_write_parquet, get_dataset_paths, hhmmss, merge_segments, set_seeds, shard_list
+
+logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
+logger = logging.getLogger("vtc_clips")
+
+CLIP_SCHEMA = pa.schema([("clip_id", pa.string()), ("onset", pa.float64()), ("offset", pa.float64()),
+                         ("duration", pa.float64()), ("label", pa.string())])
+
+
+def iter_tar_samples(tar_path):
+    """WebDataset grouping: consecutive members that share the name up to the first dot of the basename form one
+    sample {"__key__": key, ext: bytes, ...}."""
+    with tarfile.open(tar_path, "r:*") as tf:
+        key, sample = None, {}
+        for member in tf:
+            if not member.isfile():
+                continue
+            base = member.name
+            slash = base.rfind("/")
+            dot = base.find(".", slash + 1)
+            if dot < 0:
+                continue
+            k, ext = base[:dot], base[dot + 1:].lower()
+            if k != key:
+                if key is not None:
+                    yield sample
+                key, sample = k, {"__key__": k}
+            sample[ext] = tf.extractfile(member).read()
+        if key is not None:
+            yield sample
+
+
+def decode_clip(sample):
+    """Audio member of a sample -> (pcm int16/float32 (n,) or (n, ch), sample_rate).  wav is preferred here because no
+    FLAC decoder is available offline; the reference prefers flac, its packer writes wav by default
+    (src/pipeline/package.py:152)."""
+    from scipy.io import wavfile
+
+    if "wav" in sample:
+        sr, data = wavfile.read(io.BytesIO(sample["wav"]))
+        if data.dtype not in (np.int16, np.float32):
+            data = to_float32(np.asarray(data))
+        return np.array(data, order="C"), int(sr)          # own, writable copy (torch.from_numpy)
+    if "flac" in sample:
+        raise ValueError("flac clip: no FLAC decoder in this build (package with --audio_fmt wav)")
+    raise ValueError("no audio found in sample")
+
+
+def clips_table(rows: list[dict]) -> pa.Table:
+    return pa.table({"clip_id": [r["uid"] for r in rows], "onset": [r["onset"] for r in rows],
+                     "offset": [r["offset"] for r in rows], "duration": [r["duration"] for r in rows],
+                     "label": [r["label"] for r in rows]}, schema=CLIP_SCHEMA)
+
+
+def run_group(engine, group, lo, hi, labels, batch_size):
+    """group: list of (clip_id, device waveform).  One batched forward + one segmented decode -> segment rows."""
+    wavs = [w for _, w in group]
+    with torch.no_grad():
+        logits, file_rows = engine.infer_waveforms(wavs, batch_size)
+        fidx, starts, ends, lab = engine.decode_files(logits, file_rows, lo, hi)
+    per_clip = [[] for _ in group]
+    for f, s, e, k in zip(fidx, starts, ends, lab):
+        per_clip[int(f)].append((int(s), int(e), labels[int(k)]))
+    rows = []
+    for (clip_id, _), intervals in zip(group, per_clip):
+        rows.extend(intervals_to_segments(intervals, clip_id))
+    return rows
+
+
+def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
+         threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 128,
+         device: str = "cuda", array_id: int | None = None, array_count: int | None = None,
+         per_clip: bool = False) -> None:
+    set_seeds(42)
+    if device != "cuda":
+        raise SystemExit(f"vtc_amd runs on ROCm GPUs only (--device {device} requested); it has no CPU path")
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm GPU visible; vtc_amd has no CPU path")
+    paths = get_dataset_paths(dataset)
+    shard_dir = paths.output / "shards"
+    out_dir = paths.output / "vtc_clips"
+    shard_id = array_id if array_id is not None else 0
+    logger.info(f"Dataset : {dataset}")
+    logger.info(f"Shards  : {shard_dir}")
+    logger.info(f"Output  : {out_dir}")
+
+    tar_files = sorted(shard_dir.glob("*.tar"))
+    if not tar_files:
+        logger.error(f"No .tar files found in {shard_dir}")
+        sys.exit(1)
+    logger.info(f"Found {len(tar_files)} tar shards")
+    if array_id is not None and array_count is not None:
+        tar_files = shard_list(tar_files, array_id, array_count)
+        logger.info(f"Shard {array_id}/{array_count - 1}: {len(tar_files)} tars")
+
+    # ---- resume: clip_ids already present in ANY shard's raw parquet
+    raw_dir, merged_dir = out_dir / "vtc_raw", out_dir / "vtc_merged"
+    raw_path = raw_dir / f"shard_{shard_id}.parquet"
+    completed: set = set()
+    if raw_dir.exists():
+        for f in sorted(raw_dir.glob("shard_*.parquet")):
+            completed.update(pq.read_table(f, columns=["clip_id"]).column("clip_id").to_pylist())
+        if completed:
+            logger.info(f"Resume: {len(completed)} clips already done")
+
+    # ---- model
+    if Path(config).exists():
+        model_config: Config = load_config(config)
+    else:
+        logger.warning(f"config {config} not found; using built-in defaults (4 s windows, VTC_LABELS order)")
+        model_config = Config()
+    l_encoder = MultiLabelEncoder(labels=model_config.data.classes)
+    model = Models[model_config.model.name].load_from_checkpoint(
+        checkpoint_path=checkpoint, label_encoder=l_encoder, config=model_config, train=False)
+    model.eval()
+    dev_index = torch.cuda.current_device()
+    model.to(torch.device("cuda", dev_index))
+    chunk_duration_s = model_config.audio.chunk_duration_s
+    engine = model.engine(chunk_duration_s, batch_size)
+    labels = l_encoder.labels
+    lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
+    step = engine.step
+
+    seg_rows: list[dict] = []
+    n_processed = n_skipped = n_errors = 0
+    t0 = last_log_t = time.time()
+    group, group_windows = [], 0
+
+    def flush():
+        nonlocal group, group_windows, n_processed, n_errors
+        if not group:
+            return
+        try:
+            seg_rows.extend(run_group(engine, group, lo, hi, labels, batch_size))
+            n_processed += len(group)
+        except Exception as e:   # a failing batch is retried clip by clip so one bad clip cannot take the others down
+            logger.warning(f"batch of {len(group)} clips failed ({e}); retrying one by one")
+            for item in group:
+                try:
+                    seg_rows.extend(run_group(engine, [item], lo, hi, labels, batch_size))
+                    n_processed += 1
+                except Exception as e1:
+                    logger.warning(f"{item[0]}: {e1}")
+                    n_errors += 1
+        group, group_windows = [], 0
+
+    for tar_path in tar_files:
+        for sample in iter_tar_samples(tar_path):
+            clip_id = sample["__key__"]
+            if clip_id in completed:
+                n_skipped += 1
+                continue
+            try:
+                pcm, sr = decode_clip(sample)
+                wav = engine.prepare_audio(torch.from_numpy(pcm).to(engine.device), sr)
+                if wav.numel() < RF_SIZE:
+                    raise ValueError(f"audio too short: {wav.numel()} samples < receptive field {RF_SIZE}")
+            except Exception as e:
+                logger.warning(f"{clip_id}: {e}")
+                n_errors += 1
+                continue
+            group.append((clip_id, wav))
+            group_windows += max(1, -(-(int(wav.numel()) - RF_SIZE + 1) // step))
+            if per_clip or group_windows >= batch_size:
+                flush()
+            now = time.time()
+            if now - last_log_t >= 60:
+                rate = n_processed / max(now - t0, 1e-9)
+                logger.info(f"  {n_processed} processed, {n_skipped} skipped, {n_errors} errors  ({rate:.1f} clips/s)")
+                last_log_t = now
+    flush()
+
+    new_seg = clips_table(seg_rows)
+    if raw_path.exists() and completed:
+        prev = pq.read_table(raw_path).cast(CLIP_SCHEMA)
+        new_ids = pa.array(sorted({r["uid"] for r in seg_rows}), pa.string())
+        kept = prev.filter(pc.invert(pc.is_in(prev.column("clip_id"), value_set=new_ids))) if len(new_ids) else prev
+        parts = [t for t in (kept, new_seg) if t.num_rows]
+        seg_df = pa.concat_tables(parts) if parts else new_seg
+    else:
+        seg_df = new_seg
+    atomic_write_parquet(seg_df, raw_path)
+    merged = merge_segments(seg_df.rename_columns(["uid", "onset", "offset", "duration", "label"]), min_duration_off_s,
+                            min_duration_on_s).rename_columns(["clip_id", "onset", "offset", "duration", "label"])
+    atomic_write_parquet(merged, merged_dir / f"shard_{shard_id}.parquet")
+
+    wall = time.time() - t0
+    logger.info("-" * 50)
+    logger.info(f"Shard {shard_id} complete")
+    logger.info(f"  Processed : {n_processed} clips  ({n_errors} errors, {n_skipped} skipped)")
+    logger.info(f"  Segments  : {seg_df.num_rows:,} raw, {merged.num_rows:,} merged")
+    logger.info(f"  Wall time : {hhmmss(wall)}   ({n_processed / max(wall, 1e-9):.1f} clips/s)")
+    logger.info("-" * 50)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="VTC inference on clips from WebDataset shards (MI355X-native), "
+                                            "storing clip-relative segments for alignment analysis.")
+    p.add_argument("dataset", help="Dataset name (e.g. seedlings_10)")
+    p.add_argument("--config", default="VTC-2.0/model/config.yml", help="model config YAML")
+    p.add_argument("--checkpoint", default="VTC-2.0/model/best.ckpt", help="model checkpoint or 'synthetic[:seed]'")
+    p.add_argument("--threshold", type=float, default=0.5, help="Sigmoid threshold (default: 0.5)")
+    p.add_argument("--min_duration_on_s", type=float, default=0.1, help="Remove segments shorter than this (0.1 s)")
+    p.add_argument("--min_duration_off_s", type=float, default=0.3, help="Merge same-label gaps smaller than this (0.3 s)")
+    p.add_argument("--batch_size", type=int, default=128, help="Windows per forward pass, shared by the clips of a batch")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu", "mps"], help="Only 'cuda' (ROCm) is supported")
+    p.add_argument("--array_id", type=int, help="Shard index (SLURM array task ID or launcher rank)")
+    p.add_argument("--array_count", type=int, help="Number of shards")
+    p.add_argument("--per_clip", action="store_true", help="one forward + decode per clip, as the reference does (for A/B timing)")
+    return p
+
+
+if __name__ == "__main__":
+    main(**vars(build_parser().parse_args()))

@@ -19,12 +19,22 @@ struct DecodeParams {
   int nblk;
   float lo[kMaxLabels];
   float hi[kMaxLabels];
+  const unsigned char* file_start;   // optional [n + 1]: 1 where a new recording begins (runs never cross it); null = one recording
 };
 
 __device__ __forceinline__ bool frame_active(const DecodeParams& p, long long f, int l) {
   if (f < 0 || f >= p.n) return false;
   const float x = p.logits[f * p.nl + l];
   return x >= p.lo[l] && x <= p.hi[l];
+}
+// neighbours seen from frame f: the previous / next frame counts only if it belongs to the same recording
+__device__ __forceinline__ bool prev_active(const DecodeParams& p, long long f, int l) {
+  if (p.file_start && f >= 0 && f < p.n && p.file_start[f]) return false;
+  return frame_active(p, f - 1, l);
+}
+__device__ __forceinline__ bool next_active(const DecodeParams& p, long long f, int l) {
+  if (p.file_start && f + 1 < p.n && p.file_start[f + 1]) return false;
+  return frame_active(p, f + 1, l);
 }
 
 // counts: [2][nl][nblk] (0 = starts, 1 = ends); sig_sum[nblk] (fp64), max_logit[nblk]
@@ -35,8 +45,8 @@ __global__ __launch_bounds__(256) void decode_count_kernel(DecodeParams p, int* 
   float mx = -INFINITY;
   for (int l = 0; l < p.nl; ++l) {
     const bool a = frame_active(p, f, l);
-    const bool st = a && !frame_active(p, f - 1, l);
-    const bool en = a && !frame_active(p, f + 1, l);
+    const bool st = a && !prev_active(p, f, l);
+    const bool en = a && !next_active(p, f, l);
     const int cs = __syncthreads_count(st);
     const int ce = __syncthreads_count(en);
     if (threadIdx.x == 0) {
@@ -121,8 +131,8 @@ __global__ __launch_bounds__(256) void decode_emit_kernel(DecodeParams p, const 
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   for (int l = 0; l < p.nl; ++l) {
     const bool a = frame_active(p, f, l);
-    const bool st = a && !frame_active(p, f - 1, l);
-    const bool en = a && !frame_active(p, f + 1, l);
+    const bool st = a && !prev_active(p, f, l);
+    const bool en = a && !next_active(p, f, l);
     const int rs = block_rank(st, wcnt);
     const int re = block_rank(en, wcnt);
     if (st) {

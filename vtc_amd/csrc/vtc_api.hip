@@ -79,6 +79,7 @@ struct vtc_model {
   // decode scratch (grown on demand)
   long long dec_frames_cap = 0;
   int *dec_counts = nullptr, *dec_totals = nullptr, *dec_start = nullptr, *dec_end = nullptr;
+  unsigned char* dec_fstart = nullptr;
   double *dec_sig = nullptr, *dec_summary = nullptr;
   float* dec_max = nullptr;
 
@@ -336,7 +337,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
 int ensure_decode_scratch(vtc_model* m, long long n) {
   if (n <= m->dec_frames_cap) return 0;
   for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
-                  (void*)m->dec_summary, (void*)m->dec_max})
+                  (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart})
     if (p) (void)hipFree(p);
   m->dec_frames_cap = 0;
   const long long cap = n + n / 4 + 1024;
@@ -349,6 +350,7 @@ int ensure_decode_scratch(vtc_model* m, long long n) {
   HIP_TRY(m, hipMalloc((void**)&m->dec_sig, sizeof(double) * nblk));
   HIP_TRY(m, hipMalloc((void**)&m->dec_summary, sizeof(double) * 2));
   HIP_TRY(m, hipMalloc((void**)&m->dec_max, sizeof(float) * nblk));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_fstart, (size_t)cap + 1));
   m->dec_frames_cap = cap;
   return 0;
 }
@@ -372,7 +374,7 @@ void vtc_destroy(vtc_model* m) {
   (void)hipDeviceSynchronize();
   for (void* p : m->allocs) (void)hipFree(p);
   for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
-                  (void*)m->dec_summary, (void*)m->dec_max})
+                  (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart})
     if (p) (void)hipFree(p);
   if (m->h_stage) (void)hipHostFree(m->h_stage);
   for (auto& e : m->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -561,19 +563,14 @@ int vtc_infer_waveform(vtc_model* m, const float* wav, int64_t n_samples, int32_
   return VTC_OK;
 }
 
-int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi, int64_t* out_start,
-               int64_t* out_end, int32_t* out_label, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
-               void* stream) {
-  if (!m) return VTC_ERR_ARG;
-  if (!logits || !lo || !hi || !n_out || (cap > 0 && (!out_start || !out_end || !out_label)))
-    return fail(m, VTC_ERR_ARG, "null argument");
-  if (n < 1 || n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
-  HIP_TRY(m, hipSetDevice(m->device));
-  hipStream_t s = (hipStream_t)stream;
-  if (int rc = ensure_decode_scratch(m, n)) return rc;
+// Shared by vtc_decode and vtc_decode_files: runs per label as frame indices (label-major, time-ordered).
+static int decode_impl(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi,
+                       const unsigned char* file_start_dev, std::vector<int> runs_start[], std::vector<int> runs_end[],
+                       float* max_logit, double* mean_sigmoid, hipStream_t s) {
   const int nl = m->spec.n_labels;
   DecodeParams p{};
   p.logits = logits; p.n = n; p.nl = nl; p.nblk = (int)((n + 255) / 256);
+  p.file_start = file_start_dev;
   for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
   const long long dcap = m->dec_frames_cap / 2 + 1;
   LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4 * 2, s, {
@@ -589,27 +586,126 @@ int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, co
   HIP_TRY(m, hipStreamSynchronize(s));
   if (max_logit) *max_logit = (float)summary[1];
   if (mean_sigmoid) *mean_sigmoid = summary[0] / ((double)n * nl);
-  long long total = 0;
   for (int l = 0; l < nl; ++l) {
     if (totals[l] != totals[nl + l]) return fail(m, VTC_ERR_HIP, "decode: label %d has %d starts but %d ends", l, totals[l], totals[nl + l]);
-    total += totals[l];
+    const int c = totals[l];
+    runs_start[l].resize(c); runs_end[l].resize(c);
+    if (!c) continue;
+    HIP_TRY(m, hipMemcpy(runs_start[l].data(), m->dec_start + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
+    HIP_TRY(m, hipMemcpy(runs_end[l].data(), m->dec_end + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
   }
+  return VTC_OK;
+}
+
+int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi, int64_t* out_start,
+               int64_t* out_end, int32_t* out_label, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
+               void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !lo || !hi || !n_out || (cap > 0 && (!out_start || !out_end || !out_label)))
+    return fail(m, VTC_ERR_ARG, "null argument");
+  if (n < 1 || n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  HIP_TRY(m, hipSetDevice(m->device));
+  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  const int nl = m->spec.n_labels;
+  std::vector<int> rs[VTC_MAX_LABELS], re[VTC_MAX_LABELS];
+  if (int rc = decode_impl(m, logits, n, lo, hi, nullptr, rs, re, max_logit, mean_sigmoid, (hipStream_t)stream)) return rc;
+  long long total = 0;
+  for (int l = 0; l < nl; ++l) total += (long long)rs[l].size();
   *n_out = total;
   if (total > cap) return fail(m, VTC_ERR_CAPACITY, "decode: %lld intervals, caller capacity %lld", total, (long long)cap);
-  std::vector<int> hs, he;
   long long at = 0;
-  for (int l = 0; l < nl; ++l) {
-    const int c = totals[l];
-    if (!c) continue;
-    hs.resize(c); he.resize(c);
-    HIP_TRY(m, hipMemcpy(hs.data(), m->dec_start + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
-    HIP_TRY(m, hipMemcpy(he.data(), m->dec_end + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
-    for (int k = 0; k < c; ++k, ++at) {
-      out_start[at] = (int64_t)hs[k] * kRfStep;
-      out_end[at] = (int64_t)he[k] * kRfStep + kRfSize;
+  for (int l = 0; l < nl; ++l)
+    for (size_t k = 0; k < rs[l].size(); ++k, ++at) {
+      out_start[at] = (int64_t)rs[l][k] * kRfStep;
+      out_end[at] = (int64_t)re[l][k] * kRfStep + kRfSize;
       out_label[at] = l;
     }
+  return VTC_OK;
+}
+
+int vtc_infer_waveforms(vtc_model* m, const float* wav, const int64_t* offset, const int64_t* n_samples, int32_t n_files,
+                        int32_t batch, float* logits, int64_t* file_rows, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!wav || !offset || !n_samples || !logits || !file_rows) return fail(m, VTC_ERR_ARG, "null argument");
+  if (n_files < 1) return fail(m, VTC_ERR_ARG, "n_files %d < 1", n_files);
+  if (batch < 1) return fail(m, VTC_ERR_ARG, "batch %d < 1", batch);
+  if (batch > m->spec.max_batch) batch = m->spec.max_batch;
+  const long long W = m->spec.window_samples, T = m->T, step = T * kRfStep;  // chunk_artifact.py:71-73
+  std::vector<int64_t> start, dst;
+  std::vector<int32_t> valid, keep;
+  long long total = 0;
+  for (int f = 0; f < n_files; ++f) {
+    if (offset[f] < 0 || n_samples[f] < 0) return fail(m, VTC_ERR_ARG, "file %d: negative offset or length", f);
+    file_rows[f] = total;
+    for (long long s0 = 0; n_samples[f] - s0 >= kRfSize; s0 += step) {   // same plan as vtc_infer_waveform, per file
+      const long long rem = n_samples[f] - s0;
+      start.push_back(offset[f] + s0);
+      valid.push_back((int32_t)std::min(rem, W));
+      const long long k = std::min<long long>(T, vtc_frames_for_samples(rem));
+      keep.push_back((int32_t)k);
+      dst.push_back(total);
+      total += k;
+    }
   }
+  file_rows[n_files] = total;
+  for (size_t i = 0; i < start.size(); i += batch) {   // windows of different files share a forward pass
+    const int nw = (int)std::min<size_t>(batch, start.size() - i);
+    const int rc = vtc_forward_windows(m, wav, &start[i], &valid[i], &dst[i], &keep[i], nw, logits, stream);
+    if (rc) return rc;
+  }
+  return VTC_OK;
+}
+
+int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows, int32_t n_files, const float* lo,
+                     const float* hi, int32_t* out_file, int64_t* out_start, int64_t* out_end, int32_t* out_label, int64_t cap,
+                     int64_t* n_out, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !file_rows || !lo || !hi || !n_out || (cap > 0 && (!out_file || !out_start || !out_end || !out_label)))
+    return fail(m, VTC_ERR_ARG, "null argument");
+  if (n_files < 1) return fail(m, VTC_ERR_ARG, "n_files %d < 1", n_files);
+  const int64_t n = file_rows[n_files];
+  if (file_rows[0] != 0) return fail(m, VTC_ERR_ARG, "file_rows[0] must be 0");
+  for (int f = 0; f < n_files; ++f)
+    if (file_rows[f + 1] < file_rows[f]) return fail(m, VTC_ERR_ARG, "file_rows must not decrease (file %d)", f);
+  *n_out = 0;
+  if (n == 0) return VTC_OK;
+  if (n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  std::vector<unsigned char> mask((size_t)n + 1, 0);
+  for (int f = 0; f < n_files; ++f) if (file_rows[f] < n) mask[(size_t)file_rows[f]] = 1;
+  HIP_TRY(m, hipMemcpyAsync(m->dec_fstart, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
+  const int nl = m->spec.n_labels;
+  std::vector<int> rs[VTC_MAX_LABELS], re[VTC_MAX_LABELS];
+  if (int rc = decode_impl(m, logits, n, lo, hi, m->dec_fstart, rs, re, nullptr, nullptr, s)) return rc;   // synchronises s
+  long long total = 0;
+  for (int l = 0; l < nl; ++l) total += (long long)rs[l].size();
+  *n_out = total;
+  if (total > cap) return fail(m, VTC_ERR_CAPACITY, "decode: %lld intervals, caller capacity %lld", total, (long long)cap);
+  // file of each run (runs are time-ordered per label, so the file index only moves forward), then a stable
+  // counting sort by file: the result is file-major and, inside a file, label-major and time-ordered = vtc_decode per file
+  std::vector<long long> per_file((size_t)n_files + 1, 0);
+  std::vector<int> run_file[VTC_MAX_LABELS];
+  for (int l = 0; l < nl; ++l) {
+    run_file[l].resize(rs[l].size());
+    int f = 0;
+    for (size_t k = 0; k < rs[l].size(); ++k) {
+      while (f + 1 < n_files && rs[l][k] >= file_rows[f + 1]) ++f;
+      run_file[l][k] = f;
+      per_file[(size_t)f + 1]++;
+    }
+  }
+  for (int f = 0; f < n_files; ++f) per_file[(size_t)f + 1] += per_file[(size_t)f];
+  for (int l = 0; l < nl; ++l)
+    for (size_t k = 0; k < rs[l].size(); ++k) {
+      const int f = run_file[l][k];
+      const long long at = per_file[(size_t)f]++;
+      out_file[at] = f;
+      out_start[at] = ((int64_t)rs[l][k] - file_rows[f]) * kRfStep;
+      out_end[at] = ((int64_t)re[l][k] - file_rows[f]) * kRfStep + kRfSize;
+      out_label[at] = l;
+    }
   return VTC_OK;
 }
 

@@ -149,6 +149,54 @@ class VtcEngine:
                                              C.byref(nf), self._stream()), self._handle)
         return logits[: nf.value]
 
+    # ------------------------------------------------------------------ several recordings per call
+    def infer_waveforms(self, wavs, batch_size: int | None = None):
+        """List of 1-D float32 device waveforms (e.g. packaged clips) -> (logits, file_rows): stitched logits of
+        recording f are logits[file_rows[f]:file_rows[f+1]] (include/vtc_amd.h: vtc_infer_waveforms)."""
+        if not wavs:
+            raise ValueError("no waveforms")
+        for w in wavs:
+            self._check_wav(w)
+        arena = wavs[0] if len(wavs) == 1 else torch.cat(wavs)
+        n = np.asarray([int(w.numel()) for w in wavs], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int64)
+        rows = int(sum(frames_for_samples(int(k)) for k in n))
+        logits = torch.empty((max(rows, 1), self.n_labels), dtype=torch.float32, device=self.device)
+        file_rows = np.zeros(len(wavs) + 1, dtype=np.int64)
+        L.check(self._lib.vtc_infer_waveforms(self._handle, C.c_void_p(arena.data_ptr()), off.ctypes.data_as(L._i64p),
+                                              n.ctypes.data_as(L._i64p), len(wavs), int(batch_size or self.max_batch),
+                                              C.c_void_p(logits.data_ptr()), file_rows.ctypes.data_as(L._i64p),
+                                              self._stream()), self._handle)
+        arena.record_stream(torch.cuda.current_stream(self.device))
+        return logits[: int(file_rows[-1])], file_rows
+
+    def decode_files(self, logits: torch.Tensor, file_rows, lo_logit, hi_logit):
+        """Threshold + run-length decode of several recordings' rows; runs never cross a recording boundary.
+        Returns (file_index[int32], start_samples[int64], end_samples[int64], label_index[int32]), samples relative
+        to the recording (include/vtc_amd.h: vtc_decode_files)."""
+        if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
+        file_rows = np.ascontiguousarray(file_rows, dtype=np.int64)
+        n = int(file_rows[-1])
+        if n > int(logits.shape[0]):
+            raise ValueError("file_rows reach past the logits buffer")
+        lo = np.ascontiguousarray(lo_logit, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_logit, dtype=np.float32)
+        if len(lo) != self.n_labels or len(hi) != self.n_labels:
+            raise ValueError("need one lower and one upper bound per label")
+        cap = max(1024, (n // 2 + len(file_rows)) * self.n_labels)
+        fidx = np.empty(cap, dtype=np.int32)
+        s = np.empty(cap, dtype=np.int64)
+        e = np.empty(cap, dtype=np.int64)
+        lab = np.empty(cap, dtype=np.int32)
+        n_out = C.c_int64(0)
+        L.check(self._lib.vtc_decode_files(self._handle, C.c_void_p(logits.data_ptr()), file_rows.ctypes.data_as(L._i64p),
+                                           len(file_rows) - 1, lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
+                                           fidx.ctypes.data_as(L._i32p), s.ctypes.data_as(L._i64p), e.ctypes.data_as(L._i64p),
+                                           lab.ctypes.data_as(L._i32p), cap, C.byref(n_out), self._stream()), self._handle)
+        k = n_out.value
+        return fidx[:k].copy(), s[:k].copy(), e[:k].copy(), lab[:k].copy()
+
     # ------------------------------------------------------------------ audio front-end
     def prepare_audio(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:
         """Interleaved PCM on the device, int16 or float32, shape (n,) or (n, channels) -> mono float32 at 16 kHz
