@@ -9,8 +9,10 @@
 //   * O^T = V^T * P^T: the S^T accumulators, converted to 16 bit, ARE the B operand (no lane movement);
 //     the matching V^T fragments come from the row-major V image by ds_read_b64_tr_b16.
 //   * a block = 8 waves x 32 queries of one (window, head); K and V arrive in 64-key tiles by
-//     global_load_lds into a 2-stage ring (32 KiB), so several blocks share a CU and hide each other's
-//     waits.  K rows are XOR-swizzled for the ds_read_b128 fragment reads, V rows for the transposed reads.
+//     global_load_lds into a 4-stage ring (64 KiB) with three tiles in flight and a counted vmcnt: a tile's
+//     compute (~1 us) is much shorter than its load latency, so a one-deep prefetch ran at the load latency
+//     (8 tiles x ~3 us per block).  K rows are XOR-swizzled for the ds_read_b128 fragment reads, V rows for
+//     the transposed reads.
 //   * online softmax over 64 keys per step; the running-max rescale of O is skipped when no query of the
 //     wave raised its maximum (exact, wave-uniform branch).
 #pragma once
@@ -28,14 +30,28 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return d;
 }
 constexpr int kAttnStage = 16384;  // K tile 64 x 128 B, then V tile 64 x 128 B
+constexpr int kAttnStages = 4;     // ring depth: tiles kt+1 .. kt+3 are in flight while tile kt is consumed
+
+#ifdef VTC_ATTN_STAMPS   // tools/attn_bench diagnostic build
+__device__ long long g_attn_stamps[64 * 8 * 10 * 5];   // [block < 64][wave][tile < 10][point]
+__device__ long long g_attn_blk[4096 * 4];             // [block][entry, first tile ready, loop end, exit] (wave 0)
+#define ATTN_BLK(pt) do { if (threadIdx.x == 0) { const unsigned bi = blockIdx.y * gridDim.x + blockIdx.x; \
+    if (bi < 4096) g_attn_blk[bi * 4 + (pt)] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
+#define ATTN_STAMP(pt) do { if (blockIdx.x == 0 && blockIdx.y < 64 && kt < 10 && lane == 0) \
+    g_attn_stamps[((blockIdx.y * 8 + wave) * 10 + kt) * 5 + (pt)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(pt) do { } while (0)
+#define ATTN_BLK(pt) do { } while (0)
+#endif
 
 template <bool F16>
 __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx, int T, int nkt) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kAttnStage];
+  __shared__ __attribute__((aligned(16))) char smem[kAttnStages * kAttnStage];
   const int b = blockIdx.y / 12, h = blockIdx.y - b * 12;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long rowbase = (long long)b * T;
+  ATTN_BLK(0);
 
   // ---- staging: one 16-B piece of K and one of V per thread per 64-key tile
   const int srow = wave * 8 + (lane >> 3), sc = lane & 7;
@@ -74,13 +90,22 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
   const int v_row_off = (4 * hh + vq) * 128;
   const int v_col = (32 * ((lane >> 4) & 1) + 8 * (lane & 3)) ^ (((vq >> 1) & 1) << 6);   // dt = 0; dt = 1 is ^ 64
 
-  stage(0, 0);
+#pragma unroll
+  for (int t = 0; t < kAttnStages - 1; ++t)
+    if (t < nkt) stage(t, t);
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    const int cur = kt & (kAttnStages - 1);
+    // tile kt must have landed; each thread issued 2 loads per tile, in tile order, so the younger tiles may stay in flight
+    ATTN_STAMP(0);
+    const int ahead = nkt - 1 - kt;   // tiles issued after tile kt (at most kAttnStages - 2 here)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt visible to all waves; every wave is done with tile kt-1, whose stage is refilled next
+    if (kt + kAttnStages - 1 < nkt) stage((kt + kAttnStages - 1) & (kAttnStages - 1), kt + kAttnStages - 1);
+    if (kt == 0) ATTN_BLK(1);
     if (!active) continue;
+    ATTN_STAMP(1);
     const char* Ks = smem + cur * kAttnStage;
     const char* Vs = Ks + 8192;
 
@@ -106,6 +131,7 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
         if (key + 32 >= T) s1[i] = -1e30f;
       }
     }
+    ATTN_STAMP(2);
     // row maximum: v_max3 chain (the scores are MFMA results, never signalling NaNs: no canonicalising v_max needed)
     float mx = max3f(s0[0], s0[1], s0[2]);
 #pragma unroll
@@ -132,6 +158,7 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
       psum1 += s1[i];
     }
     l += psum0 + psum1;
+    ATTN_STAMP(3);
 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -155,22 +182,45 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
         }
       }
     }
+    ATTN_STAMP(4);
   }
-  if (!active) return;
-
   l += __shfl_xor(l, 32);
   const float inv = 1.f / l;
-  const int q = q0 + r;
-  if (q < T) {
-    h16* dst = ctx + (rowbase + q) * 768 + h * 64 + 4 * hh;
+  // Epilogue through the (now idle) K/V ring: the wave parks its 32 x 64 context tile as 16-bit rows in a private
+  // 4 KiB region (16-B chunk index XOR (row & 7): conflict-free for the b64 writes and the b128 reads), then every
+  // lane stores 16 B with 8 lanes per 128-B row: 4 store instructions per wave instead of 16 row-scattered 8-B ones
+  // (store issue, not bandwidth, is what the tail of this kernel costs).
+  ATTN_BLK(2);
+  __syncthreads();   // every wave is past its last K/V read
+  if (!active) return;
+  char* park = smem + wave * 4096;
+  {
+    const int sw = r & 7;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      *(uint2*)(dst + 8 * g) = make_uint2(pack2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                          pack2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-      *(uint2*)(dst + 32 + 8 * g) = make_uint2(pack2<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                               pack2<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+      // d = 8 g + 4 hh .. +4 (o0) and 32 + 8 g + 4 hh .. (o1): 8-B half (hh) of 16-B chunk g / 4 + g
+      const uint2 a = make_uint2(pack2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      const uint2 b = make_uint2(pack2<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+      *(uint2*)(park + r * 128 + ((g ^ sw) << 4) + 8 * hh) = a;
+      *(uint2*)(park + r * 128 + (((4 + g) ^ sw) << 4) + 8 * hh) = b;
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int c = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const uint4 v = *(const uint4*)(park + row * 128 + ((c ^ (row & 7)) << 4));
+      const int q = q0 + row;
+      if (q < T) *(uint4*)(ctx + (rowbase + q) * 768 + h * 64 + c * 8) = v;
+    }
+  }
+#ifdef VTC_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ATTN_BLK(3);
 }
 
 }  // namespace vtc
