@@ -100,9 +100,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a box with fewer GPUs than ranks: VTC_BENCH_REHEARSE=1 puts every rank on the visible GPUs round-robin
+    # and uses gloo for the timing barrier / max (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearse = os.environ.get("VTC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -155,7 +163,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read() if not args.no_profile else None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
