@@ -262,6 +262,26 @@ def test_daylong_16h_recording_properties(weights):
     eng.close()
 
 
+def test_large_batch_outputs_over_2gib(weights):
+    """Batch 400 x 4 s windows: the conv1 / conv2 outputs exceed 2 GiB, which the persistent GEMM's 32-bit buffer
+    offsets cannot address in one launch; gemm_go cuts such a GEMM into row chunks of whole windows.  Periodic input,
+    so every window (on either side of a chunk boundary) must reproduce window 0 bit for bit."""
+    chunk, B = 4.0, 400
+    eng = _engine(weights, chunk, B)
+    T, W, step = eng.frames_per_window, eng.window_samples, eng.step
+    assert (T, W, step) == (199, 64000, 63680)
+    period = torch.from_numpy(synth.synth_audio(step / 16000.0, seed=23)[:step]).cuda()
+    wav = period.repeat(B + 1)[: (B - 1) * step + W].contiguous()
+    logits = eng.infer_waveform(wav, batch_size=B)
+    torch.cuda.synchronize()
+    assert logits.shape == (B * T, 4)
+    tiled = logits.view(B, T, 4)
+    assert torch.equal(tiled, tiled[0:1].expand(B, T, 4))
+    ref0 = O.apply_model_on_waveform(weights, wav[:W].cpu().numpy(), chunk)
+    assert (tiled[0].cpu() - ref0).abs().max().item() <= LOGIT_TOL
+    eng.close()
+
+
 def test_bf16_mode_error_is_measured_and_bounded(weights):
     """bf16 MFMA operands cannot meet the 2e-2 bar on this model (DESIGN.md 'Precision'); the mode stays
     selectable and its error is pinned here so a regression shows."""

@@ -208,8 +208,29 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   // Tile choice (measured with tools/gemm_bench): the persistent 256 x BN kernel needs N % BN == 0 and
   // K % 128 == 0 (>= 256); BN = 192 where N allows and its rounds x width are no worse (N = 768, 2304, 3072:
   // the 192-wide kernel has no register spills and a cheaper epilogue), BN = 256 otherwise (conv, N = 512).
-  // the persistent kernel's epilogue addresses C through 32-bit buffer offsets
-  const bool fits32 = (long long)p.M * p.ldc * ((EPI & EPI_F32) ? 4 : 2) < (1ll << 31);
+  // The persistent kernel's epilogue addresses C (and the residual) through 32-bit buffer offsets: an output larger than
+  // 2 GiB (large batches of short windows: conv1 at batch 512 x 4 s is 3.3 GB) is cut into row chunks of whole
+  // windows, each its own launch over the same weights.
+  constexpr long long kEsz = (EPI & EPI_F32) ? 4 : 2;
+  if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.K >= 256 && p.M >= 4096 && nz == 1 &&
+      (long long)p.M * p.ldc * kEsz >= (1ll << 31)) {
+    const long long unit = p.rows_per_batch < p.M ? p.rows_per_batch : 256;       // rows that may start a chunk
+    long long rows_max = ((1ll << 31) - 1) / ((long long)p.ldc * kEsz);
+    rows_max = rows_max / unit * unit;
+    if (rows_max >= 4096) {
+      for (long long r0 = 0; r0 < p.M; r0 += rows_max) {
+        GemmParams q = p;
+        q.M = (int)std::min<long long>(rows_max, p.M - r0);
+        if (p.rows_per_batch < p.M) q.A = p.A + (r0 / p.rows_per_batch) * p.a_batch_stride;
+        else { q.A = p.A + r0 * p.a_row_stride; q.rows_per_batch = q.M; }
+        q.C = (char*)p.C + r0 * p.ldc * kEsz;
+        if (p.resid) q.resid = (const float*)((const char*)p.resid + r0 * p.ldc * ((EPI & EPI_RESID16) ? 2 : 4));
+        gemm_go<F16, BN, EPI>(m, q, nz, s);
+      }
+      return;
+    }
+  }
+  const bool fits32 = (long long)p.M * p.ldc * kEsz < (1ll << 31);
   if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.K >= 256 && p.M >= 4096 && fits32) {
     // rounds of tiles over the 256 CUs x tile width ~ time
     const long long tm = (p.M + 255) / 256;
