@@ -117,11 +117,13 @@ int vtc_infer_waveforms(vtc_model* m, const float* wav /*[dev]*/, const int64_t*
                         int64_t* file_rows /*[host] n_files+1, out*/, void* stream);
 /* vtc_decode over such a row layout: runs never cross a recording boundary, out_start / out_end are samples relative
  * to the recording, output is recording-major and inside a recording label-major, time-ordered (= vtc_decode on each
- * recording's rows).  No sigmoid summary.  Synchronises `stream`. */
+ * recording's rows).  max_logit / mean_sigmoid (each [n_files], may be null) receive the per-recording sigmoid
+ * summary of src/pipeline/vtc.py:266-273.  Synchronises `stream`. */
 int vtc_decode_files(vtc_model* m, const float* logits /*[dev]*/, const int64_t* file_rows /*[host] n_files+1*/,
                      int32_t n_files, const float* lo_logit /*[host]*/, const float* hi_logit /*[host]*/,
                      int32_t* out_file /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,
-                     int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, void* stream);
+                     int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit /*[host]*/,
+                     double* mean_sigmoid /*[host]*/, void* stream);
 
 /* Audio front-end of apply_model_on_audio (src/pipeline/vtc.py:236-243 decodes the file to mono 16 kHz float inside
  * segma before the model runs): interleaved PCM already in device memory -> mono float32 at 16 kHz, on `stream`.

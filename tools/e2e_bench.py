@@ -35,6 +35,7 @@ def main() -> None:
     ap.add_argument("--chunk", type=float, default=10.0)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--prefetch", type=int, default=4)
+    ap.add_argument("--no_group", action="store_true", help="one forward per file (A/B against cross-file batching)")
     ap.add_argument("--dir", default=None, help="scratch directory (default: a fresh temp dir, /dev/shm if present)")
     args = ap.parse_args()
 
@@ -61,7 +62,8 @@ def main() -> None:
     cli.main("warm", config=str(root / "cfg.yml"), checkpoint="synthetic:0", batch_size=args.batch, prefetch=args.prefetch)
     torch.cuda.synchronize()
     t0 = time.time()
-    cli.main("c2", config=str(root / "cfg.yml"), checkpoint="synthetic:0", batch_size=args.batch, prefetch=args.prefetch)
+    cli.main("c2", config=str(root / "cfg.yml"), checkpoint="synthetic:0", batch_size=args.batch, prefetch=args.prefetch,
+             no_group=args.no_group)
     torch.cuda.synchronize()
     wall = time.time() - t0
     hours = args.files * args.seconds / 3600.0
@@ -74,7 +76,7 @@ def main() -> None:
                       "note": "value includes model construction + weight packing (once per process); steady_state_value is "
                               "the CLI's own file loop + parquet writes", "files": args.files, "file_seconds": args.seconds,
                       "audio_hours": hours, "wall_s": wall, "raw_segments": n_raw, "generate_s": gen_s,
-                      "chunk_duration_s": args.chunk, "batch": args.batch, "prefetch": args.prefetch}), flush=True)
+                      "chunk_duration_s": args.chunk, "batch": args.batch, "prefetch": args.prefetch, "no_group": args.no_group}), flush=True)
     if not args.dir:
         import shutil
         shutil.rmtree(root, ignore_errors=True)

@@ -146,4 +146,29 @@ __global__ __launch_bounds__(256) void decode_emit_kernel(DecodeParams p, const 
   }
 }
 
+// Per-recording sigmoid summary for vtc_decode_files: one block per recording, fixed summation order (thread-strided
+// partials, then wave and block reduction): out[2 f] = sum of sigmoid over rows x labels (fp64), out[2 f + 1] = max logit.
+__global__ __launch_bounds__(256) void file_summary_kernel(const float* __restrict__ logits, int nl, const long long* __restrict__ rows,
+                                                           double* __restrict__ out) {
+  const int f = blockIdx.x;
+  const long long e0 = rows[f] * nl, e1 = rows[f + 1] * nl;
+  double ssum = 0.0;
+  float mx = -INFINITY;
+  for (long long i = e0 + threadIdx.x; i < e1; i += 256) {
+    const float x = logits[i];
+    ssum += (double)(1.f / (1.f + __expf(-x)));
+    mx = fmaxf(mx, x);
+  }
+  __shared__ double rs[4];
+  __shared__ float rm[4];
+  ssum = wave_sum_d(ssum);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = ssum; rm[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * f] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    out[2 * f + 1] = (double)fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+  }
+}
+
 }  // namespace vtc

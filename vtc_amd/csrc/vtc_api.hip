@@ -80,6 +80,9 @@ struct vtc_model {
   long long dec_frames_cap = 0;
   int *dec_counts = nullptr, *dec_totals = nullptr, *dec_start = nullptr, *dec_end = nullptr;
   unsigned char* dec_fstart = nullptr;
+  long long* fsum_rows = nullptr;   // vtc_decode_files per-recording summary scratch
+  double* fsum_out = nullptr;
+  int fsum_cap = 0;
   double *dec_sig = nullptr, *dec_summary = nullptr;
   float* dec_max = nullptr;
 
@@ -395,7 +398,7 @@ void vtc_destroy(vtc_model* m) {
   (void)hipDeviceSynchronize();
   for (void* p : m->allocs) (void)hipFree(p);
   for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
-                  (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart})
+                  (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart, (void*)m->fsum_rows, (void*)m->fsum_out})
     if (p) (void)hipFree(p);
   if (m->h_stage) (void)hipHostFree(m->h_stage);
   for (auto& e : m->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -679,7 +682,7 @@ int vtc_infer_waveforms(vtc_model* m, const float* wav, const int64_t* offset, c
 
 int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows, int32_t n_files, const float* lo,
                      const float* hi, int32_t* out_file, int64_t* out_start, int64_t* out_end, int32_t* out_label, int64_t cap,
-                     int64_t* n_out, void* stream) {
+                     int64_t* n_out, float* max_logit, double* mean_sigmoid, void* stream) {
   if (!m) return VTC_ERR_ARG;
   if (!logits || !file_rows || !lo || !hi || !n_out || (cap > 0 && (!out_file || !out_start || !out_end || !out_label)))
     return fail(m, VTC_ERR_ARG, "null argument");
@@ -698,8 +701,31 @@ int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows
   for (int f = 0; f < n_files; ++f) if (file_rows[f] < n) mask[(size_t)file_rows[f]] = 1;
   HIP_TRY(m, hipMemcpyAsync(m->dec_fstart, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
   const int nl = m->spec.n_labels;
+  if (max_logit || mean_sigmoid) {   // per-recording sigmoid summary (vtc.py:266-273), one block per recording
+    if (n_files > m->fsum_cap) {
+      if (m->fsum_rows) (void)hipFree(m->fsum_rows);
+      if (m->fsum_out) (void)hipFree(m->fsum_out);
+      m->fsum_rows = nullptr; m->fsum_out = nullptr; m->fsum_cap = 0;
+      const int capf = n_files + n_files / 2 + 64;
+      HIP_TRY(m, hipMalloc((void**)&m->fsum_rows, sizeof(long long) * (capf + 1)));
+      HIP_TRY(m, hipMalloc((void**)&m->fsum_out, sizeof(double) * 2 * capf));
+      m->fsum_cap = capf;
+    }
+    HIP_TRY(m, hipMemcpyAsync(m->fsum_rows, file_rows, sizeof(long long) * (n_files + 1), hipMemcpyHostToDevice, s));
+    LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4, s,
+           hipLaunchKernelGGL(file_summary_kernel, dim3(n_files), dim3(256), 0, s, logits, nl, m->fsum_rows, m->fsum_out));
+  }
   std::vector<int> rs[VTC_MAX_LABELS], re[VTC_MAX_LABELS];
   if (int rc = decode_impl(m, logits, n, lo, hi, m->dec_fstart, rs, re, nullptr, nullptr, s)) return rc;   // synchronises s
+  if (max_logit || mean_sigmoid) {
+    std::vector<double> hsum((size_t)2 * n_files);
+    HIP_TRY(m, hipMemcpy(hsum.data(), m->fsum_out, sizeof(double) * 2 * n_files, hipMemcpyDeviceToHost));
+    for (int f = 0; f < n_files; ++f) {
+      const long long cnt = (file_rows[f + 1] - file_rows[f]) * nl;
+      if (max_logit) max_logit[f] = cnt ? (float)hsum[2 * f + 1] : -INFINITY;
+      if (mean_sigmoid) mean_sigmoid[f] = cnt ? hsum[2 * f] / (double)cnt : 0.0;
+    }
+  }
   long long total = 0;
   for (int l = 0; l < nl; ++l) total += (long long)rs[l].size();
   *n_out = total;

@@ -170,10 +170,11 @@ class VtcEngine:
         arena.record_stream(torch.cuda.current_stream(self.device))
         return logits[: int(file_rows[-1])], file_rows
 
-    def decode_files(self, logits: torch.Tensor, file_rows, lo_logit, hi_logit):
+    def decode_files(self, logits: torch.Tensor, file_rows, lo_logit, hi_logit, summary: bool = False):
         """Threshold + run-length decode of several recordings' rows; runs never cross a recording boundary.
         Returns (file_index[int32], start_samples[int64], end_samples[int64], label_index[int32]), samples relative
-        to the recording (include/vtc_amd.h: vtc_decode_files)."""
+        to the recording (include/vtc_amd.h: vtc_decode_files); with summary=True also (max_logit[float32],
+        mean_sigmoid[float64]) per recording."""
         if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
             raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
         file_rows = np.ascontiguousarray(file_rows, dtype=np.int64)
@@ -190,12 +191,18 @@ class VtcEngine:
         e = np.empty(cap, dtype=np.int64)
         lab = np.empty(cap, dtype=np.int32)
         n_out = C.c_int64(0)
+        nf = len(file_rows) - 1
+        mx = np.empty(nf, dtype=np.float32) if summary else None
+        mean = np.empty(nf, dtype=np.float64) if summary else None
         L.check(self._lib.vtc_decode_files(self._handle, C.c_void_p(logits.data_ptr()), file_rows.ctypes.data_as(L._i64p),
-                                           len(file_rows) - 1, lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
+                                           nf, lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
                                            fidx.ctypes.data_as(L._i32p), s.ctypes.data_as(L._i64p), e.ctypes.data_as(L._i64p),
-                                           lab.ctypes.data_as(L._i32p), cap, C.byref(n_out), self._stream()), self._handle)
+                                           lab.ctypes.data_as(L._i32p), cap, C.byref(n_out),
+                                           mx.ctypes.data_as(L._f32p) if summary else None,
+                                           mean.ctypes.data_as(L._f64p) if summary else None, self._stream()), self._handle)
         k = n_out.value
-        return fidx[:k].copy(), s[:k].copy(), e[:k].copy(), lab[:k].copy()
+        out = (fidx[:k].copy(), s[:k].copy(), e[:k].copy(), lab[:k].copy())
+        return out + (mx, mean) if summary else out
 
     # ------------------------------------------------------------------ audio front-end
     def prepare_audio(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:

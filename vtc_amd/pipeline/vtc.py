@@ -26,6 +26,8 @@ import os
 import sys
 import threading
 import time
+from collections import deque
+from concurrent.futures import Future
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
@@ -117,6 +119,25 @@ def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logit
     return starts, ends, lab, max_logit, mean_sig, int(gpu_wav.numel()), cpu_logits
 
 
+def gpu_group_stage(engine, wavs, lo, hi, batch_size: int, want_logits: bool):
+    """GPU-thread stage for several short recordings: their windows share forward passes (vtc_infer_waveforms) and one
+    segmented decode with per-recording sigmoid summaries (vtc_decode_files).  Returns one gpu_stage-shaped tuple per
+    recording.  A 30 s file is 8 windows of 4 s: alone it would use 1/16 of a 128-window batch."""
+    cur = torch.cuda.current_stream(engine.device)
+    for w in wavs:
+        w.record_stream(cur)
+    with torch.no_grad():
+        logits, rows = engine.infer_waveforms(wavs, batch_size)
+        fidx, starts, ends, lab, mx, mean = engine.decode_files(logits, rows, lo, hi, summary=True)
+        bounds = np.searchsorted(fidx, np.arange(len(wavs) + 1))      # fidx is sorted (recording-major output)
+        out = []
+        for f, w in enumerate(wavs):
+            a, b = int(bounds[f]), int(bounds[f + 1])
+            cpu_logits = logits[int(rows[f]):int(rows[f + 1])].cpu() if want_logits else None
+            out.append((starts[a:b], ends[a:b], lab[a:b], float(mx[f]), float(mean[f]), int(w.numel()), cpu_logits))
+    return out
+
+
 def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
     """Host stage: triples -> segment rows + meta row (reference vtc.py:252-281)."""
     starts, ends, lab, max_logit, mean_sig, _, cpu_logits = decoded
@@ -141,7 +162,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
          threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 0,
          save_logits: bool = False, device: str = "cuda", array_id: int | None = None,
          array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False,
-         flush_every: int = 0, flush_seconds: float = 300.0):
+         flush_every: int = 0, flush_seconds: float = 300.0, no_group: bool = False):
     set_seeds(42)
     if device != "cuda":
         raise SystemExit(f"vtc_amd runs on ROCm GPUs only (--device {device} requested); it has no CPU path")
@@ -271,50 +292,119 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     depth = max(1, prefetch)
     save_to = logits_dir if save_logits else None
 
-    def gpu_job(audio_future):
-        torch.cuda.set_device(engine.device)
-        return gpu_stage(engine, audio_future.result(), lo, hi, batch_size, save_logits)
+    step = engine.step
+    results = [Future() for _ in range(total)]
+    stop = threading.Event()
+    read_budget = 1 << 30          # bytes of files being staged ahead of the GPU (short files are read far ahead to fill batches)
+    max_ahead = 256
 
-    with ThreadPoolExecutor(max_workers=depth) as readers, ThreadPoolExecutor(max_workers=1) as gpu_thread:
-        pending = {}
-        nxt = 0
+    def gpu_worker(readers):
+        """Pulls staged recordings in manifest order; recordings shorter than a batch are grouped until the batch is
+        full (or until waiting for the next one would idle the GPU) and run together; long ones run alone."""
+        torch.cuda.set_device(engine.device)
+        inflight, nxt, inflight_bytes = deque(), 0, 0
+        group, group_windows = [], 0
 
         def top_up():
-            nonlocal nxt
-            while nxt < total and len(pending) < depth + 1:
-                audio = readers.submit(stage_audio, uid_to_path[todo[nxt]], engine)
-                pending[nxt] = gpu_thread.submit(gpu_job, audio)
+            nonlocal nxt, inflight_bytes
+            while nxt < total and (len(inflight) < depth + 1 or
+                                   (len(inflight) < max_ahead and inflight_bytes + sizes.get(todo[nxt], 0) <= read_budget)):
+                inflight.append((nxt, readers.submit(stage_audio, uid_to_path[todo[nxt]], engine)))
+                inflight_bytes += sizes.get(todo[nxt], 0)
                 nxt += 1
 
-        top_up()
-        for i, uid in enumerate(todo):
-            fut = pending.pop(i)
-            top_up()
+        def run_group():
+            nonlocal group, group_windows
+            if not group:
+                return
+            items, group, group_windows = group, [], 0
             try:
-                decoded = fut.result()
-                segs, row = finish_file(decoded, uid, threshold, labels, save_to)
-                audio_seconds += decoded[5] / 16000.0
-            except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
-                n_errors += 1
-                logger.warning(f"{uid}: {e}")
-                meta_rows.append(vtc_error_row(uid, str(e)))
-                continue
-            seg_rows.extend(segs)
-            meta_rows.append(row)
-            bytes_done += sizes.get(uid, 0)
-            now = time.time()
-            since_flush += 1
-            if i + 1 < total and ((flush_every > 0 and since_flush >= flush_every) or
-                                  (flush_seconds > 0 and now - last_flush >= flush_seconds)):
-                write_outputs(final=False)
-                since_flush, last_flush = 0, time.time()
-            if (i + 1) % log_every == 0 or i + 1 == total or now - last_log >= 60:
-                rate = bytes_done / max(now - t0, 1e-9)
-                eta_s = (total_bytes - bytes_done) / rate if rate > 0 else 0
-                eta = f"{eta_s / 60:.0f}m" if eta_s < 3600 else f"{eta_s / 3600:.1f}h"
-                print(f"  VTC  {i + 1:>4}/{total}  {bytes_done / 1e9:.1f}/{total_bytes / 1e9:.1f} GB"
-                      f" ({100.0 * bytes_done / total_bytes:.0f}%)  ETA {eta}", flush=True)
-                last_log = now
+                if len(items) == 1:
+                    outs = [gpu_stage(engine, items[0][1], lo, hi, batch_size, save_logits)]
+                else:
+                    outs = gpu_group_stage(engine, [w for _, w in items], lo, hi, batch_size, save_logits)
+                for (i, _), o in zip(items, outs):
+                    results[i].set_result(o)
+            except Exception as e:
+                if len(items) == 1:
+                    results[items[0][0]].set_exception(e)
+                    return
+                for i, w in items:       # one bad recording must not take its batch mates down: redo them one by one
+                    try:
+                        results[i].set_result(gpu_stage(engine, w, lo, hi, batch_size, save_logits))
+                    except Exception as e1:
+                        results[i].set_exception(e1)
+
+        try:
+            top_up()
+            while inflight and not stop.is_set():
+                i, fut = inflight.popleft()
+                inflight_bytes -= sizes.get(todo[i], 0)
+                top_up()
+                if group and not fut.done():
+                    run_group()          # the next recording is not staged yet: do not hold a partial batch back
+                try:
+                    wav = fut.result()
+                except Exception as e:
+                    results[i].set_exception(e)
+                    continue
+                n_win = -(-(int(wav.numel()) - RF_SIZE + 1) // step)
+                if no_group or n_win >= batch_size:
+                    run_group()
+                    group, group_windows = [(i, wav)], n_win
+                    run_group()
+                    continue
+                if group and group_windows + n_win > batch_size:
+                    run_group()
+                group.append((i, wav))
+                group_windows += n_win
+                if group_windows >= batch_size:
+                    run_group()
+            run_group()
+        except BaseException as e:       # never leave the consumer waiting on a future that will not resolve
+            for f in results:
+                if not f.done():
+                    f.set_exception(RuntimeError(f"GPU worker stopped: {e}"))
+            raise
+        finally:
+            for _, f in inflight:
+                f.cancel()
+            for f in results:
+                if not f.done():
+                    f.set_exception(RuntimeError("run stopped before this file was processed"))
+
+    with ThreadPoolExecutor(max_workers=depth) as readers, ThreadPoolExecutor(max_workers=1) as gpu_thread:
+        worker = gpu_thread.submit(gpu_worker, readers)
+        try:
+            for i, uid in enumerate(todo):
+                try:
+                    decoded = results[i].result()
+                    segs, row = finish_file(decoded, uid, threshold, labels, save_to)
+                    audio_seconds += decoded[5] / 16000.0
+                except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
+                    n_errors += 1
+                    logger.warning(f"{uid}: {e}")
+                    meta_rows.append(vtc_error_row(uid, str(e)))
+                    continue
+                seg_rows.extend(segs)
+                meta_rows.append(row)
+                bytes_done += sizes.get(uid, 0)
+                now = time.time()
+                since_flush += 1
+                if i + 1 < total and ((flush_every > 0 and since_flush >= flush_every) or
+                                      (flush_seconds > 0 and now - last_flush >= flush_seconds)):
+                    write_outputs(final=False)
+                    since_flush, last_flush = 0, time.time()
+                if (i + 1) % log_every == 0 or i + 1 == total or now - last_log >= 60:
+                    rate = bytes_done / max(now - t0, 1e-9)
+                    eta_s = (total_bytes - bytes_done) / rate if rate > 0 else 0
+                    eta = f"{eta_s / 60:.0f}m" if eta_s < 3600 else f"{eta_s / 3600:.1f}h"
+                    print(f"  VTC  {i + 1:>4}/{total}  {bytes_done / 1e9:.1f}/{total_bytes / 1e9:.1f} GB"
+                          f" ({100.0 * bytes_done / total_bytes:.0f}%)  ETA {eta}", flush=True)
+                    last_log = now
+        finally:
+            stop.set()          # an interrupt here must not leave the worker chewing through the rest of the manifest
+        worker.result()
 
     seg_df, merged_df = write_outputs(final=True)
 
@@ -358,6 +448,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--flush_seconds", type=float, default=300.0,
                    help="write the shard's parquet files at least this often while running (0 = only at the end); a crash "
                         "then loses at most this much work and the resume rule picks up from the flushed files")
+    p.add_argument("--no_group", action="store_true",
+                   help="one forward per file even when a file is shorter than a batch of windows (the reference's pattern; A/B timing)")
     add_sample_argument(p)
     return p
 
