@@ -332,58 +332,74 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const h16* __restrict
 }
 
 // IN16: the input rows are 16-bit (the GEMM epilogue that produced them rounded once more); else fp32.
+// A wave handles kLnRows rows at once: all their loads are issued before the first reduction, which doubles the bytes
+// in flight per wave (the kernel is a pure stream over rows that the producing GEMM left in L2 / Infinity Cache).
+constexpr int kLnRows = 2;
+
 template <bool F16, bool HEAD, bool IN16 = false>
 __global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restrict__ in, const float* __restrict__ g,
                                                            const float* __restrict__ bt, float* __restrict__ out32,
                                                            h16* __restrict__ out16, int rows, HeadParams hp) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLnRows;
+  if (row0 >= rows) return;
   const int lane = threadIdx.x & 63;
-  float v[12];
-  float s = 0.f;
+  float v[kLnRows][12];
+  float s[kLnRows];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float4 x;
-    if constexpr (IN16) {
-      const u16x4 h = *(const u16x4*)((const h16*)in + (long long)row * 768 + i * 256 + lane * 4);
-      x = make_float4(from_h16<F16>(h[0]), from_h16<F16>(h[1]), from_h16<F16>(h[2]), from_h16<F16>(h[3]));
-    } else {
-      x = *(const float4*)((const float*)in + (long long)row * 768 + i * 256 + lane * 4);
-    }
-    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-    s += (x.x + x.y) + (x.z + x.w);
-  }
-  const float mean = wave_sum(s) * (1.f / 768.f);
-  float q = 0.f;
+  for (int r = 0; r < kLnRows; ++r) {
+    const int row = min(row0 + r, rows - 1);   // a clamped duplicate row is computed and not stored
+    s[r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
-  const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + 1e-5f);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int c = i * 256 + lane * 4;
-    const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(bt + c);
-    v[4 * i] = fmaf(v[4 * i] * rstd, gg.x, bb.x);
-    v[4 * i + 1] = fmaf(v[4 * i + 1] * rstd, gg.y, bb.y);
-    v[4 * i + 2] = fmaf(v[4 * i + 2] * rstd, gg.z, bb.z);
-    v[4 * i + 3] = fmaf(v[4 * i + 3] * rstd, gg.w, bb.w);
-    if (out32) *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-    *(uint2*)(out16 + (long long)row * 768 + c) =
-        make_uint2(pack2<F16>(v[4 * i], v[4 * i + 1]), pack2<F16>(v[4 * i + 2], v[4 * i + 3]));
-  }
-  if constexpr (HEAD) {
-    const int b = row / hp.T, t = row - b * hp.T;
-    const bool keep = t < hp.wt.keep[b];
-    const long long dst = hp.wt.dst_row[b] + t;
-    for (int l = 0; l < hp.n_labels; ++l) {
-      float d = 0.f;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float4 ww = *(const float4*)(hp.w + l * 768 + i * 256 + lane * 4);
-        d = fmaf(v[4 * i], ww.x, d); d = fmaf(v[4 * i + 1], ww.y, d);
-        d = fmaf(v[4 * i + 2], ww.z, d); d = fmaf(v[4 * i + 3], ww.w, d);
+    for (int i = 0; i < 3; ++i) {
+      float4 x;
+      if constexpr (IN16) {
+        const u16x4 h = *(const u16x4*)((const h16*)in + (long long)row * 768 + i * 256 + lane * 4);
+        x = make_float4(from_h16<F16>(h[0]), from_h16<F16>(h[1]), from_h16<F16>(h[2]), from_h16<F16>(h[3]));
+      } else {
+        x = *(const float4*)((const float*)in + (long long)row * 768 + i * 256 + lane * 4);
       }
-      d = wave_sum(d);
-      if (lane == 0 && keep) hp.logits[dst * hp.n_labels + l] = d + hp.b[l];
+      v[r][4 * i] = x.x; v[r][4 * i + 1] = x.y; v[r][4 * i + 2] = x.z; v[r][4 * i + 3] = x.w;
+      s[r] += (x.x + x.y) + (x.z + x.w);
+    }
+  }
+  float4 gg[3], bb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gg[i] = *(const float4*)(g + i * 256 + lane * 4); bb[i] = *(const float4*)(bt + i * 256 + lane * 4); }
+#pragma unroll
+  for (int r = 0; r < kLnRows; ++r) {
+    const int row = row0 + r;
+    const float mean = wave_sum(s[r]) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { v[r][i] -= mean; q = fmaf(v[r][i], v[r][i], q); }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + 1e-5f);
+    if (row >= rows) break;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      v[r][4 * i] = fmaf(v[r][4 * i] * rstd, gg[i].x, bb[i].x);
+      v[r][4 * i + 1] = fmaf(v[r][4 * i + 1] * rstd, gg[i].y, bb[i].y);
+      v[r][4 * i + 2] = fmaf(v[r][4 * i + 2] * rstd, gg[i].z, bb[i].z);
+      v[r][4 * i + 3] = fmaf(v[r][4 * i + 3] * rstd, gg[i].w, bb[i].w);
+      if (out32) *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[r][4 * i], v[r][4 * i + 1], v[r][4 * i + 2], v[r][4 * i + 3]);
+      *(uint2*)(out16 + (long long)row * 768 + c) =
+          make_uint2(pack2<F16>(v[r][4 * i], v[r][4 * i + 1]), pack2<F16>(v[r][4 * i + 2], v[r][4 * i + 3]));
+    }
+    if constexpr (HEAD) {
+      const int b = row / hp.T, t = row - b * hp.T;
+      const bool keep = t < hp.wt.keep[b];
+      const long long dst = hp.wt.dst_row[b] + t;
+      for (int l = 0; l < hp.n_labels; ++l) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float4 ww = *(const float4*)(hp.w + l * 768 + i * 256 + lane * 4);
+          d = fmaf(v[r][4 * i], ww.x, d); d = fmaf(v[r][4 * i + 1], ww.y, d);
+          d = fmaf(v[r][4 * i + 2], ww.z, d); d = fmaf(v[r][4 * i + 3], ww.w, d);
+        }
+        d = wave_sum(d);
+        if (lane == 0 && keep) hp.logits[dst * hp.n_labels + l] = d + hp.b[l];
+      }
     }
   }
 }

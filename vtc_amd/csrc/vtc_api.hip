@@ -310,7 +310,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
                             m->pos_w, m->pos_b, m->h0, m->tmp32, T));
   HeadParams nohead{};
   LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-         hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), dim3((M + 3) / 4), dim3(256), 0, s, (const void*)m->tmp32, m->enc_ln_w,
+         hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), dim3((M + 4 * kLnRows - 1) / (4 * kLnRows)), dim3(256), 0, s, (const void*)m->tmp32, m->enc_ln_w,
                             m->enc_ln_b, (float*)nullptr, m->x16, M, nohead));
   if (m->debug_stop == 8) return 0;
 
@@ -334,7 +334,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
     auto ln768 = [&](const float* g, const float* b, bool head) {
       const double bytes = (double)M * 768 * (m->pre_ln16 ? 4 : 6);
       HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
-      const dim3 grid((M + 3) / 4), blk(256);
+      const dim3 grid((M + 4 * kLnRows - 1) / (4 * kLnRows)), blk(256);
       if (head) {   // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
         if (m->pre_ln16)
           LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, true, true>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, hp));
