@@ -92,7 +92,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=120, help="windows of the bounded CPU-oracle sample (~15 s on 16 cores)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
-    ap.add_argument("--profile-every", type=int, default=5,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="steps of the timed region whose launches are bracketed by HIP events: every n-th (two event "
                          "records per launch cost ~7 us of stream time, ~0.75 ms per fully profiled step)")
     args = ap.parse_args()
