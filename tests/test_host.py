@@ -327,3 +327,35 @@ def test_host_resampler_matches_oracle_restatement_of_torchaudio():
     y = audio.sinc_resample(np.sin(2 * np.pi * 440 * t).astype(np.float32), 48000)
     assert np.abs(y[200:-200] - np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000.0)[200:-200]).max() < 1e-3
     assert np.array_equal(audio.sinc_resample(np.ones(5, np.float32), 16000), np.ones(5, np.float32))
+
+
+def test_clip_tar_iterator_and_wav_decode(tmp_path):
+    """Host side of the clips caller (no GPU): WebDataset grouping of tar members by key, in-memory WAV decode,
+    the errors the caller turns into skipped clips."""
+    import io, tarfile
+    from scipy.io import wavfile
+    from vtc_amd.analysis.vtc_on_clips import decode_clip, iter_tar_samples
+
+    def add(tf, name, data):
+        info = tarfile.TarInfo(name)
+        info.size = len(data)
+        tf.addfile(info, io.BytesIO(data))
+
+    buf = io.BytesIO()
+    x = (np.sin(np.arange(8000) / 10.0) * 20000).astype(np.int16)
+    wavfile.write(buf, 16000, x)
+    with tarfile.open(tmp_path / "s.tar", "w") as tf:
+        add(tf, "a_0000.wav", buf.getvalue())
+        add(tf, "a_0000.json", b"{}")
+        add(tf, "dir/b_0001.seg.json", b"{}")
+        add(tf, "dir/b_0001.flac", b"fLaC")
+        add(tf, "c_0002.txt", b"nothing")
+    samples = list(iter_tar_samples(tmp_path / "s.tar"))
+    assert [s_["__key__"] for s_ in samples] == ["a_0000", "dir/b_0001", "c_0002"]
+    assert set(samples[0]) == {"__key__", "wav", "json"} and set(samples[1]) == {"__key__", "seg.json", "flac"}
+    pcm, sr = decode_clip(samples[0])
+    assert sr == 16000 and pcm.dtype == np.int16 and np.array_equal(pcm, x) and pcm.flags.writeable
+    with pytest.raises(ValueError, match="FLAC"):
+        decode_clip(samples[1])
+    with pytest.raises(ValueError, match="no audio"):
+        decode_clip(samples[2])
