@@ -333,6 +333,29 @@ def test_decode_bit_exact_against_oracle(weights):
     eng.close()
 
 
+@pytest.mark.parametrize("n_labels", [1, 3, 8])
+def test_other_label_counts(n_labels):
+    """The head width is data (cfg.data.classes, SURVEY 8c: label set unpinned): 1, 3 and the maximum of 8 labels
+    through forward + decode against the oracle."""
+    from vtc_amd.engine import VtcEngine
+    labels = tuple(f"L{i}" for i in range(n_labels))
+    w = O.make_weights(seed=5, n_labels=n_labels)
+    wav = synth.synth_audio(5.3, seed=61)
+    ref = O.apply_model_on_waveform(w, wav, 2.0)
+    eng = VtcEngine(w, n_labels=n_labels, chunk_duration_s=2.0, max_batch=2, device=0)
+    got = eng.infer_waveform(torch.from_numpy(wav).cuda())
+    assert got.shape == ref.shape == (O.n_frames_for_samples(len(wav)), n_labels)
+    assert (got.cpu() - ref).abs().max().item() <= LOGIT_TOL
+    thr = {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in labels}
+    lo, hi = logit_bounds(thr, labels)
+    s, e, lab, _, _ = eng.decode(got.contiguous(), lo, hi)
+    mask = O.apply_thresholds(got.cpu(), thr, labels)
+    assert [(int(a), int(b), labels[int(c)]) for a, b, c in zip(s, e, lab)] == O.create_intervals(mask, labels)
+    eng.close()
+    with pytest.raises(Exception):
+        VtcEngine(w, n_labels=n_labels + 1, chunk_duration_s=2.0, max_batch=2, device=0)   # head shape mismatch
+
+
 # ----------------------------------------------------------------------------- drop-in surface + CLI
 def test_reference_host_flow_through_segma_surface(weights, tmp_path):
     """The reference's own call sequence (src/pipeline/vtc.py:183-195, 236-243, 84-96, 284-288)."""
