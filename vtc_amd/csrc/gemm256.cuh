@@ -439,10 +439,22 @@ template <bool F16, int EPI, int BN>
 inline void launch_gemm256(GemmParams p, int nz, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / BN;
-  // largest divisor of tiles_n whose W panel (group_n x BN x K 16-bit) stays within ~2.5 MB of the XCD's 4 MiB L2
-  p.group_n = 1;
-  for (int g = 1; g <= p.tiles_n; ++g)
-    if (p.tiles_n % g == 0 && (long long)g * BN * p.K * 2 <= (5ll << 19)) p.group_n = g;
+  // Column-group width: the divisor g of tiles_n with the least estimated fabric traffic.  A is re-read once per group
+  // (tiles_n / g times); a group's W panel is fetched once per XCD when it fits beside the streaming A rows in the
+  // 4 MiB L2 (<= 2.5 MB), otherwise once per XCD and round of tiles.
+  {
+    const double a_bytes = 2.0 * p.M * (p.a_row_stride < p.K ? p.a_row_stride : p.K);
+    const double w_bytes = 2.0 * p.N * p.K;
+    const double rounds = (double)p.tiles_m * p.tiles_n / 256.0;
+    double best = 1e300;
+    p.group_n = p.tiles_n;
+    for (int g = 1; g <= p.tiles_n; ++g) {
+      if (p.tiles_n % g) continue;
+      const bool fits = (double)g * BN * p.K * 2 <= 2.5e6;
+      const double est = a_bytes * (p.tiles_n / g) + w_bytes * 8.0 * (fits ? 1.0 : (rounds > 1.0 ? rounds : 1.0));
+      if (est < best) { best = est; p.group_n = g; }
+    }
+  }
 #ifdef VTC_STAMPS
   if (const char* e = getenv("VTC_GROUP_N")) {   // diagnostic override, only a positive divisor of tiles_n is taken
     const int g = atoi(e);
