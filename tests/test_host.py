@@ -359,3 +359,36 @@ def test_clip_tar_iterator_and_wav_decode(tmp_path):
         decode_clip(samples[1])
     with pytest.raises(ValueError, match="no audio"):
         decode_clip(samples[2])
+
+
+def test_fast_wav_reader_matches_scipy(tmp_path):
+    """audio.read_pcm's own RIFF parser (PCM16 / float32, mono and multi-channel, extra chunks, odd chunk sizes) against
+    scipy.io.wavfile; other sample formats fall back to scipy."""
+    import struct
+    from scipy.io import wavfile
+    from vtc_amd import audio
+    rng = np.random.default_rng(9)
+    cases = {"m16.wav": (16000, (rng.standard_normal(5001) * 8000).astype(np.int16)),
+             "s16.wav": (44100, (rng.standard_normal((777, 2)) * 8000).astype(np.int16)),
+             "f32.wav": (48000, rng.standard_normal((300, 3)).astype(np.float32) * 0.1),
+             "u8.wav": (8000, rng.integers(0, 255, 400).astype(np.uint8)),
+             "i32.wav": (16000, (rng.standard_normal(400) * 1e8).astype(np.int32))}
+    for name, (sr, x) in cases.items():
+        wavfile.write(tmp_path / name, sr, x)
+        got, gsr = audio.read_pcm(tmp_path / name)
+        assert gsr == sr
+        if x.dtype in (np.int16, np.float32):
+            assert audio._fast_wav(tmp_path / name) is not None
+            assert got.dtype == x.dtype and np.array_equal(got, x)
+        else:
+            assert audio._fast_wav(tmp_path / name) is None and got.dtype == np.float32
+    # a LIST chunk of odd length before the data chunk, and a data size field larger than the file (truncated recording)
+    raw = (tmp_path / "m16.wav").read_bytes()
+    i = raw.index(b"data")
+    odd = raw[:i] + b"LIST" + struct.pack("<I", 5) + b"abcde\0" + b"data" + struct.pack("<I", 0xFFFFFFF0) + raw[i + 8:]
+    (tmp_path / "odd.wav").write_bytes(odd)
+    got, gsr = audio.read_pcm(tmp_path / "odd.wav")
+    assert gsr == 16000 and np.array_equal(got, cases["m16.wav"][1])
+    (tmp_path / "junk.wav").write_bytes(b"not a wav file at all")
+    with pytest.raises(Exception):
+        audio.read_pcm(tmp_path / "junk.wav")

@@ -11,6 +11,7 @@ mixed / resampled there: the pipeline's route) and `read_audio` (all on the host
 
 from __future__ import annotations
 
+import os
 from math import gcd
 from pathlib import Path
 
@@ -33,14 +34,61 @@ def to_float32(data: np.ndarray) -> np.ndarray:
     return out
 
 
+def _fast_wav(path: Path):
+    """Minimal RIFF/WAVE reader for the two formats the GPU front-end takes as they are (PCM16, float32): one header
+    parse and one read (small files) or a memory map (large ones).  Returns None for anything else - scipy handles it."""
+    import struct
+
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            return None
+        fmt = None
+        while True:
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                return None
+            cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+            if cid == b"fmt ":
+                body = f.read(size + (size & 1))
+                if size < 16:
+                    return None
+                tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+                if tag == 0xFFFE and size >= 40:                       # WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the tag
+                    tag = struct.unpack("<H", body[24:26])[0]
+                fmt = (tag, ch, sr, bits)
+            elif cid == b"data":
+                if fmt is None:
+                    return None
+                tag, ch, sr, bits = fmt
+                dtype = np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else None
+                if dtype is None or ch < 1:
+                    return None
+                offset = f.tell()
+                avail = os.fstat(f.fileno()).st_size - offset
+                nbytes = min(size, avail) if size not in (0, 0xFFFFFFFF) else avail
+                frame = ch * np.dtype(dtype).itemsize
+                n = nbytes // frame
+                if n * frame >= (8 << 20):
+                    data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(n * ch,))
+                else:
+                    data = np.fromfile(f, dtype=dtype, count=n * ch)
+                return (data.reshape(n, ch) if ch > 1 else data), int(sr)
+            else:
+                f.seek(size + (size & 1), 1)
+
+
 def read_pcm(path):
     """Decode only as far as the container: (samples, sample_rate) with samples int16 or float32, shape (n,) or
-    (n, channels), memory-mapped when the format allows.  Mixing and resampling are left to the GPU."""
-    from scipy.io import wavfile
-
+    (n, channels), memory-mapped when large.  Mixing and resampling are left to the GPU."""
     path = Path(path)
     if path.suffix.lower() not in (".wav", ".wave"):
         raise ValueError(f"{path.name}: only WAV input is supported by this build (got '{path.suffix}')")
+    fast = _fast_wav(path)
+    if fast is not None:
+        return fast
+    from scipy.io import wavfile
+
     try:
         sr, data = wavfile.read(str(path), mmap=True)
     except ValueError:

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,6 +92,7 @@ struct vtc_model {
 
   struct ResampleDev { ResampleTable t; };
   std::map<int, ResampleDev> resample;   // per input sample rate, built on first use (vtc_prepare_audio)
+  std::mutex resample_mu;                // vtc_prepare_audio is called from several reader threads
   bool prof_on = false;
   bool conv0_mfma = true;  // conv0 as one fp16-split MFMA per 16 x 16 outputs (env VTC_CONV0_MFMA=0: VALU form)
   bool pre_ln16 = false;   // pre-LayerNorm rows of the transformer layers in 16 bit (default: on for fp16; env VTC_PRE_LN16)
@@ -797,6 +799,7 @@ int64_t vtc_resampled_length(int64_t n_in, int32_t sr_in) {
 // torchaudio.functional.resample's kernel (_get_sinc_resample_kernel, sinc_interp_hann, width 6, rolloff 0.99), fp64 -> fp32,
 // stored compactly: per phase only the taps inside the window's support (|w| >= 1e-30; the clamped taps outside are ~1e-34).
 static int build_resample(vtc_model* m, int sr_in, ResampleTable* out) {
+  std::lock_guard<std::mutex> lock(m->resample_mu);
   auto it = m->resample.find(sr_in);
   if (it != m->resample.end()) { *out = it->second.t; return VTC_OK; }
   long long a = sr_in, b = 16000;

@@ -54,6 +54,13 @@ logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", date
 logger = logging.getLogger("vtc")
 
 _TLS = threading.local()
+STAGE_SECONDS = {"read": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0, "finish": 0.0}   # summed wall time per stage (logged at the end)
+_TIMER_LOCK = threading.Lock()
+
+
+def _tick(name: str, t0: float) -> None:
+    with _TIMER_LOCK:
+        STAGE_SECONDS[name] += time.perf_counter() - t0
 
 # VRAM -> windows per forward pass; same table as the reference (src/pipeline/resources.py:180-188).
 _BATCH_TABLE = [(80, 512), (48, 256), (32, 192), (24, 128), (16, 64), (0, 32)]
@@ -93,16 +100,21 @@ def stage_audio(path, engine) -> torch.Tensor:
     """Reader-thread stage: read the file's raw PCM (int16 / float32, any channel count and rate), copy it to HBM on this
     thread's own stream and run the GPU front-end there (channel mix, resample to 16 kHz, float32), so that decode,
     H2D and front-end of file i+1 overlap the forward of file i.  Returns only after the waveform is ready."""
+    t0 = time.perf_counter()
     pcm, sr = read_pcm(path)
     device = engine.device
     copy_stream = getattr(_TLS, "stream", None)
     if copy_stream is None:
         copy_stream = _TLS.stream = torch.cuda.Stream(device)
-    host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=pcm.size >= (1 << 18))
-    np.copyto(host.numpy(), pcm)                      # page cache / mmap -> pinned staging, no conversion on the host
+    if isinstance(pcm, np.memmap) or pcm.nbytes >= (8 << 20) or not pcm.flags.writeable:
+        host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=True)
+        np.copyto(host.numpy(), pcm)                  # page cache / mmap -> pinned staging, no conversion on the host
+    else:
+        host = torch.from_numpy(pcm)                  # small file, already in memory: a pageable copy is cheaper than pinning
     with torch.cuda.stream(copy_stream):
         wav = engine.prepare_audio(host.to(device, non_blocking=True), sr)
     copy_stream.synchronize()
+    _tick("read", t0)
     if wav.numel() < RF_SIZE:
         raise ValueError(f"audio too short: {wav.numel()} samples < receptive field {RF_SIZE}")
     return wav
@@ -164,6 +176,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
          array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False,
          flush_every: int = 0, flush_seconds: float = 300.0, no_group: bool = False):
     set_seeds(42)
+    for k in STAGE_SECONDS:
+        STAGE_SECONDS[k] = 0.0
     if device != "cuda":
         raise SystemExit(f"vtc_amd runs on ROCm GPUs only (--device {device} requested); it has no CPU path")
     if not torch.cuda.is_available():
@@ -318,6 +332,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             if not group:
                 return
             items, group, group_windows = group, [], 0
+            t_run = time.perf_counter()
             try:
                 if len(items) == 1:
                     outs = [gpu_stage(engine, items[0][1], lo, hi, batch_size, save_logits)]
@@ -325,6 +340,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     outs = gpu_group_stage(engine, [w for _, w in items], lo, hi, batch_size, save_logits)
                 for (i, _), o in zip(items, outs):
                     results[i].set_result(o)
+                _tick("gpu_run", t_run)
             except Exception as e:
                 if len(items) == 1:
                     results[items[0][0]].set_exception(e)
@@ -343,11 +359,14 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 top_up()
                 if group and not fut.done():
                     run_group()          # the next recording is not staged yet: do not hold a partial batch back
+                t_wait = time.perf_counter()
                 try:
                     wav = fut.result()
                 except Exception as e:
                     results[i].set_exception(e)
                     continue
+                finally:
+                    _tick("gpu_wait", t_wait)
                 n_win = -(-(int(wav.numel()) - RF_SIZE + 1) // step)
                 if no_group or n_win >= batch_size:
                     run_group()
@@ -379,7 +398,9 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             for i, uid in enumerate(todo):
                 try:
                     decoded = results[i].result()
+                    t_fin = time.perf_counter()
                     segs, row = finish_file(decoded, uid, threshold, labels, save_to)
+                    _tick("finish", t_fin)
                     audio_seconds += decoded[5] / 16000.0
                 except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
                     n_errors += 1
@@ -416,6 +437,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     logger.info(f"  Threshold : {threshold}")
     logger.info(f"  Segments  : {seg_df.num_rows:,} raw, {merged_df.num_rows:,} merged")
     logger.info(f"  Wall time : {hhmmss(wall)}   ({audio_seconds / 3600.0 / max(wall, 1e-9):.3f} audio-hours/s)")
+    logger.info("  Stage time: " + ", ".join(f"{k} {v:.2f}s" for k, v in STAGE_SECONDS.items()) +
+                f"  (read is summed over {depth} reader threads; wall {wall:.2f}s)")
     logger.info("-" * 50)
     done_bytes = sum(os.path.getsize(uid_to_path[u]) for u in todo if os.path.exists(uid_to_path[u]))
     log_benchmark(step="vtc", dataset=dataset, n_files=total, wall_seconds=wall, total_audio_seconds=audio_seconds,
