@@ -73,7 +73,8 @@ typedef struct {
  * Packs the weights for the MFMA kernels, uploads them and allocates the activation workspace. */
 int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model** out);
 void vtc_destroy(vtc_model* m);
-/* Message of the last failure on `m` (or of the last failed vtc_create when m == NULL). */
+/* Message of the last failure on `m` (m == NULL: of the last failed handle-less call, vtc_create or vtc_flac_*, on
+ * the calling thread). */
 const char* vtc_last_error(const vtc_model* m);
 
 /* Stands behind: model.conv_settings (vtc.py:194) -- frames per window T, and the frame count of a file. */
@@ -136,6 +137,21 @@ int vtc_decode_files(vtc_model* m, const float* logits /*[dev]*/, const int64_t*
 int64_t vtc_resampled_length(int64_t n_in, int32_t sr_in);
 int vtc_prepare_audio(vtc_model* m, const void* pcm /*[dev] n_in x n_channels, interleaved*/, int32_t format, int64_t n_in,
                       int32_t n_channels, int32_t sr_in, float* out /*[dev]*/, int64_t out_cap, int64_t* n_out, void* stream);
+
+/* FLAC members of the audio front-end (host side, no GPU work, no handle): the reference's packaged clips are FLAC by
+ * default (src/packaging/writer.py:36,119; src/analysis/vtc_on_clips.py:163-166 prefers the .flac member) and manifests
+ * may list .flac recordings (scripts/make_manifest.py:26-39); the reference decodes them with torchcodec/ffmpeg inside
+ * segma.  Decoder of RFC 9639 streams held in memory (an ID3v2 tag in front is skipped): frame header CRC-8 and frame
+ * CRC-16 are checked; the decoded integers are exactly the encoder's input (lossless), STREAMINFO's MD5 is returned so
+ * the caller can verify them.  vtc_flac_info: n_samples = inter-channel samples, 0 if the stream does not say.
+ * vtc_flac_decode writes interleaved samples: out_format 0 = int16 as stored (streams of <= 16 bits per sample),
+ * 1 = float32 = integer / 2^(bits-1), 2 = int32 as stored; out == NULL only counts.  VTC_ERR_CAPACITY if out_cap
+ * (inter-channel samples) is too small.  Thread-safe; the message of a failure is vtc_last_error(NULL) on the
+ * calling thread. */
+int vtc_flac_info(const void* data /*[host]*/, int64_t n_bytes, int32_t* sample_rate, int32_t* n_channels,
+                  int32_t* bits_per_sample, int64_t* n_samples, uint8_t* md5 /*[16] or NULL*/);
+int vtc_flac_decode(const void* data /*[host]*/, int64_t n_bytes, void* out /*[host]*/, int32_t out_format,
+                    int64_t out_cap, int64_t* n_out);
 
 /* Test hook: copy an intermediate activation of the LAST vtc_forward_windows call to the host as fp32.
  * stage: 0..6 conv layer outputs (B,L_i,512); 7 projection (B*T,768); 8 encoder input after pos-conv+LN;

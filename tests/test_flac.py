@@ -1,0 +1,178 @@
+"""FLAC / AIFF members of the audio front-end: the library's host-side decoder against the
+RFC 9639 example stream, against the pure-Python oracle decoder, and through lossless round trips with the test encoder
+of oracle/flac_codec.py (every subframe type, Rice width, escape partition, wasted bits, stereo mode, sample size).
+CPU only: vtc_flac_* do no device work."""
+
+import ctypes as C
+import json
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import flac_codec as F
+from vtc_amd import lib as L
+from vtc_amd.audio import decode_aiff, decode_flac, read_audio, read_pcm, write_wav
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def tone(n, nch, bps, seed=0):
+    rng = np.random.default_rng(seed)
+    amp = (1 << (bps - 1)) * 0.4
+    t = np.arange(n)
+    x = amp * np.sin(2 * np.pi * t * 220 / 16000)[:, None] * np.array([1.0, 0.7])[:nch] + rng.normal(0, amp * 0.01, (n, nch))
+    return x.astype(np.int64)
+
+
+def as_decoded(x, bps):
+    """What decode_flac returns for integer input x: int16 as stored for 16-bit streams, else integer / 2^(bps-1)."""
+    y = x.astype(np.int16) if bps == 16 else (x / float(1 << (bps - 1))).astype(np.float32)
+    return y[:, 0] if y.shape[1] == 1 else y
+
+
+def test_rfc9639_example_stream():
+    g = json.loads((GOLDEN / "flac_rfc9639_example1.json").read_text())
+    data = bytes.fromhex(g["stream_hex"])
+    want = np.array(g["samples"], dtype=np.int64)
+    pcm, info = F.decode(data)                       # oracle: CRC-8, CRC-16 and MD5 of the stream all verified inside
+    assert np.array_equal(pcm, want)
+    assert (info["sample_rate"], info["channels"], info["bps"], info["total"]) == (44100, 2, 16, 1)
+    got, sr = decode_flac(data, verify_md5=True)     # product decoder
+    assert sr == g["sample_rate"] and got.dtype == np.int16 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("bps", [8, 12, 16, 20, 24])
+@pytest.mark.parametrize("nch", [1, 2])
+def test_lossless_round_trip_all_subframe_types(bps, nch):
+    x = tone(9000, nch, bps, seed=bps * 2 + nch)
+    stereo_modes = ("auto", "independent", "left_side", "side_right", "mid_side") if nch == 2 else ("independent",)
+    for sub in ("auto", "verbatim", "fixed0", "fixed1", "fixed2", "fixed3", "fixed4", "lpc", "constant"):
+        for st in stereo_modes:
+            for wide, esc in ((False, False), (True, True)):
+                xx = np.full_like(x, -37) if sub == "constant" else x
+                if sub == "fixed2":
+                    xx = (xx >> 3) << 3                                   # wasted bits
+                enc = F.encode(xx, 16000, bps=bps, blocksize=4096 if not wide else 1000,
+                               subframe="auto" if sub == "constant" else sub, stereo=st, porder=3, wide_rice=wide,
+                               escape=esc, with_total=not esc)
+                got, sr = decode_flac(enc, verify_md5=True)
+                want = as_decoded(xx, bps)
+                assert sr == 16000
+                assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), (sub, st, wide)
+
+
+def test_product_decoder_matches_oracle_decoder():
+    x = tone(2500, 2, 16, seed=3)
+    for kw in (dict(subframe="lpc", stereo="mid_side", blocksize=576, lpc_order=12, lpc_prec=14),
+               dict(subframe="auto", stereo="left_side", blocksize=192, wide_rice=True, escape=True),
+               dict(subframe="fixed4", stereo="side_right", variable_blocks=[576, 192, 1000, 17]),
+               dict(subframe="lpc", stereo="independent", blocksize=300, lpc_order=32, lpc_prec=15, with_total=False),
+               dict(subframe="verbatim", stereo="auto", blocksize=4096, extra_metadata=False)):
+        enc = F.encode(x, 44100, **kw)
+        ref, info = F.decode(enc)
+        got, sr = decode_flac(enc, verify_md5=True)
+        assert np.array_equal(ref, x) and np.array_equal(got, ref.astype(np.int16)) and sr == 44100
+
+
+def test_extreme_values_and_32_bit():
+    for bps in (16, 24, 32):
+        lo, hi = -(1 << (bps - 1)), (1 << (bps - 1)) - 1
+        rng = np.random.default_rng(bps)
+        x = rng.integers(lo, hi + 1, size=(3000, 2), dtype=np.int64)
+        x[:4] = [[lo, hi], [hi, lo], [lo, lo], [hi, hi]]
+        for st in ("independent", "mid_side", "left_side", "side_right"):          # the side channel needs bps+1 bits
+            enc = F.encode(x, 48000, bps=bps, subframe="verbatim" if st != "independent" else "fixed1", stereo=st,
+                           wide_rice=True, blocksize=1024)
+            ref, _ = F.decode(enc[:])
+            assert np.array_equal(ref, x)
+            n, got = C.c_int64(), np.empty((3000, 2), dtype=np.int32)
+            L.check(L.load().vtc_flac_decode(enc, len(enc), C.c_void_p(got.ctypes.data), 2, 3000, C.byref(n)))
+            assert n.value == 3000 and np.array_equal(got, x)
+
+
+def test_id3_prefix_unknown_length_and_trailing_bytes():
+    x = tone(5000, 1, 16)
+    enc = F.encode(x, 16000, with_total=False)
+    tag = b"ID3\x04\x00\x00" + bytes([0, 0, 0, 20]) + bytes(20)
+    got, _ = decode_flac(tag + enc)
+    assert np.array_equal(got, x[:, 0])
+    enc2 = F.encode(x, 16000) + b"TAG" + bytes(125)           # ID3v1 tag after the last frame
+    got2, _ = decode_flac(enc2, verify_md5=True)
+    assert np.array_equal(got2, x[:, 0])
+
+
+def test_damaged_streams_raise():
+    x = tone(9000, 1, 16)
+    enc = bytearray(F.encode(x, 16000))
+    with pytest.raises(L.VtcError, match="fLaC"):
+        decode_flac(b"RIFF" + bytes(enc[4:]))
+    bad = bytearray(enc)
+    bad[len(bad) // 2] ^= 0x10                                 # one flipped bit in the middle of a frame
+    with pytest.raises(L.VtcError, match="CRC|sync|subframe|Rice|residual|reserved"):
+        decode_flac(bytes(bad))
+    with pytest.raises(L.VtcError, match="ends after|truncated|CRC|sync"):
+        decode_flac(bytes(enc[: len(enc) * 2 // 3]))
+    with pytest.raises(L.VtcError, match="metadata|STREAMINFO"):
+        decode_flac(bytes(enc[:20]))
+    hdr = bytearray(enc)
+    hdr[F.stream_info(bytes(enc))["audio_offset"] + 2] ^= 0x01  # frame header byte: CRC-8 must catch it
+    with pytest.raises(L.VtcError, match="header CRC|reserved|invalid"):
+        decode_flac(bytes(hdr))
+    wrong = bytearray(enc)
+    wrong[4 + 4 + 18] ^= 0xFF                                  # STREAMINFO MD5
+    with pytest.raises(ValueError, match="MD5"):
+        decode_flac(bytes(wrong), verify_md5=True)
+    n = C.c_int64()
+    out = np.empty(100, dtype=np.int16)
+    rc = L.load().vtc_flac_decode(bytes(enc), len(enc), C.c_void_p(out.ctypes.data), 0, 100, C.byref(n))
+    assert rc == L.ERR_CAPACITY
+    enc24 = F.encode(tone(100, 1, 24), 16000, bps=24)
+    rc = L.load().vtc_flac_decode(enc24, len(enc24), C.c_void_p(out.ctypes.data), 0, 100, C.byref(n))
+    assert rc == L.ERR_ARG and "16 bits" in L.last_error(None)
+
+
+def test_flac_file_reads_like_the_wav_of_the_same_samples(tmp_path):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((44100 * 2, 2)) * 3000).astype(np.int16)
+    from scipy.io import wavfile
+
+    wavfile.write(tmp_path / "a.wav", 44100, x)
+    (tmp_path / "a.flac").write_bytes(F.encode(x.astype(np.int64), 44100, subframe="lpc"))
+    pw, srw = read_pcm(tmp_path / "a.wav")
+    pf, srf = read_pcm(tmp_path / "a.flac")
+    assert srw == srf == 44100 and pf.dtype == np.int16 and np.array_equal(np.asarray(pw), pf)
+    assert np.array_equal(read_audio(tmp_path / "a.wav"), read_audio(tmp_path / "a.flac"))     # mono mix + resample too
+    with pytest.raises(ValueError, match="codec"):
+        read_pcm(tmp_path / "a.mp3")
+
+
+def test_aiff_against_the_standard_library_writer(tmp_path):
+    import aifc                                                 # stdlib (deprecated, present in 3.10): independent writer
+    import warnings
+
+    rng = np.random.default_rng(6)
+    for width, nch, rate in ((2, 2, 44100), (2, 1, 16000), (3, 1, 22050), (1, 2, 8000), (4, 1, 48000)):
+        bits = width * 8
+        x = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(4000, nch), dtype=np.int64)
+        raw = x.astype(">i8").view(np.uint8).reshape(-1, 8)[:, 8 - width:].tobytes()
+        path = tmp_path / f"a{width}{nch}.aiff"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with aifc.open(str(path), "wb") as f:
+                f.setnchannels(nch)
+                f.setsampwidth(width)
+                f.setframerate(rate)
+                f.writeframes(raw)
+        got, sr = read_pcm(path)
+        want = x.astype(np.int16) if width == 2 else (x / float(1 << (bits - 1))).astype(np.float32)
+        want = want[:, 0] if nch == 1 else want
+        assert sr == rate and got.dtype == want.dtype and np.array_equal(got, want), (width, nch)
+    # AIFF-C little-endian PCM ('sowt'), written by hand
+    x = rng.integers(-32768, 32768, size=(1000, 2), dtype=np.int64).astype(np.int16)
+    comm = struct.pack(">hIh", 2, 1000, 16) + struct.pack(">HQ", 16383 + 15, 48000 << 48) + b"sowt" + b"\x00\x00"
+    ssnd = struct.pack(">II", 0, 0) + x.astype("<i2").tobytes()
+    body = b"AIFC" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd
+    got, sr = decode_aiff(b"FORM" + struct.pack(">I", len(body)) + body)
+    assert sr == 48000 and np.array_equal(got, x)

@@ -541,6 +541,49 @@ def test_cli_accepts_stereo_44k_file(weights, tmp_path, monkeypatch):
     assert meta[0]["uid"] == "s44" and meta[0]["error"] == ""
 
 
+def test_cli_flac_and_aiff_inputs_equal_wav(weights, tmp_path, monkeypatch):
+    """The same PCM16 samples as .wav, .flac (library decoder) and .aiff give identical segments and meta rows through
+    the CLI; a 24-bit FLAC (float path) agrees with the oracle on its own samples; an .mp3 becomes an error row."""
+    import aifc, warnings
+    from scipy.io import wavfile
+    from oracle import flac_codec as FL
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    x = synth.synth_audio(21.3, seed=77)
+    up = np.interp(np.arange(int(21.3 * 22050)) / 22050.0, np.arange(len(x)) / 16000.0, x)
+    pcm = np.clip(np.round(np.stack([up, 0.3 * up], axis=1) * 32768), -32768, 32767).astype(np.int16)
+    wavfile.write(tmp_path / "audio" / "a_wav.wav", 22050, pcm)
+    (tmp_path / "audio" / "a_flac.flac").write_bytes(FL.encode(pcm.astype(np.int64), 22050, subframe="lpc"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with aifc.open(str(tmp_path / "audio" / "a_aiff.aiff"), "wb") as f:
+            f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050)
+            f.writeframes(pcm.astype(">i2").tobytes())
+    x24 = np.clip(np.round(x.astype(np.float64) * (1 << 23)), -(1 << 23), (1 << 23) - 1).astype(np.int64)
+    (tmp_path / "audio" / "b24.flac").write_bytes(FL.encode(x24, 16000, bps=24))
+    (tmp_path / "audio" / "c.mp3").write_bytes(b"ID3" + bytes(64))
+    names = ["a_wav.wav", "a_flac.flac", "a_aiff.aiff", "b24.flac", "c.mp3"]
+    (tmp_path / "manifests" / "mix.csv").write_text("path\n" + "".join(f"{tmp_path / 'audio' / n}\n" for n in names))
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    cli.main("mix", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8, save_logits=True)
+    out = tmp_path / "output" / "mix"
+    seg = pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist()
+    meta = {r["uid"]: r for r in pq.read_table(out / "vtc_meta" / "shard_0.parquet").to_pylist()}
+    by = lambda uid: [(r["onset"], r["offset"], r["label"]) for r in seg if r["uid"] == uid]
+    assert len(by("a_wav")) > 0 and by("a_wav") == by("a_flac") == by("a_aiff")
+    for k in ("vtc_speech_dur", "vtc_n_segments", "vtc_label_counts", "vtc_max_sigmoid", "vtc_mean_sigmoid", "error"):
+        assert meta["a_wav"][k] == meta["a_flac"][k] == meta["a_aiff"][k], k
+    la, lb = (torch.load(out / "logits" / f"{u}-logits_dict_t.pt", weights_only=True) for u in ("a_wav", "a_flac"))
+    assert all(torch.equal(la[l], lb[l]) for l in O.DEFAULT_LABELS)
+    saved = torch.load(out / "logits" / "b24-logits_dict_t.pt", weights_only=True)
+    got = torch.stack([saved[l] for l in O.DEFAULT_LABELS], dim=1)
+    ref = O.apply_model_on_waveform(weights, (x24 / float(1 << 23)).astype(np.float32), 4.0)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= LOGIT_TOL
+    assert "codec" in meta["c"]["error"] and meta["b24"]["error"] == ""
+
+
 # ----------------------------------------------------------------------------- several recordings per call (clips)
 def test_multi_recording_batch_equals_per_recording(weights):
     """vtc_infer_waveforms / vtc_decode_files: windows of many short recordings share forward passes; rows and decoded
@@ -579,6 +622,7 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
     segments out, resume by clip_id, per-clip errors counted and skipped."""
     import io, tarfile
     from scipy.io import wavfile
+    from oracle import flac_codec as FL
     from vtc_amd.analysis import vtc_on_clips as clips
     monkeypatch.chdir(tmp_path)
     shard_dir = tmp_path / "output" / "ds" / "shards"
@@ -605,7 +649,12 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
                 cid = f"uidA_{k:04d}"
                 x = synth.synth_audio(2.0 + 1.7 * c, seed=300 + k)
                 audio[cid] = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
-                add(tf, f"{cid}.wav", wav_bytes(x))
+                if c % 2 == 1:                                  # the reference's packer writes flac by default
+                    add(tf, f"{cid}.flac", FL.encode(audio[cid].astype(np.int64), 16000, subframe="lpc" if c == 1 else "auto"))
+                else:
+                    add(tf, f"{cid}.wav", wav_bytes(x))
+                if c == 3:                                      # both members: flac wins (vtc_on_clips.py:163-166)
+                    add(tf, f"{cid}.wav", wav_bytes(np.zeros_like(x)))
                 add(tf, f"{cid}.json", b"{}")
                 k += 1
             if t == 0:

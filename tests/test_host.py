@@ -334,6 +334,7 @@ def test_clip_tar_iterator_and_wav_decode(tmp_path):
     the errors the caller turns into skipped clips."""
     import io, tarfile
     from scipy.io import wavfile
+    from oracle import flac_codec as FL
     from vtc_amd.analysis.vtc_on_clips import decode_clip, iter_tar_samples
 
     def add(tf, name, data):
@@ -348,17 +349,20 @@ def test_clip_tar_iterator_and_wav_decode(tmp_path):
         add(tf, "a_0000.wav", buf.getvalue())
         add(tf, "a_0000.json", b"{}")
         add(tf, "dir/b_0001.seg.json", b"{}")
-        add(tf, "dir/b_0001.flac", b"fLaC")
+        add(tf, "dir/b_0001.flac", FL.encode(x.astype(np.int64)[::-1], 16000))
         add(tf, "c_0002.txt", b"nothing")
+        add(tf, "d_0003.flac", b"fLaC")
     samples = list(iter_tar_samples(tmp_path / "s.tar"))
-    assert [s_["__key__"] for s_ in samples] == ["a_0000", "dir/b_0001", "c_0002"]
+    assert [s_["__key__"] for s_ in samples] == ["a_0000", "dir/b_0001", "c_0002", "d_0003"]
     assert set(samples[0]) == {"__key__", "wav", "json"} and set(samples[1]) == {"__key__", "seg.json", "flac"}
     pcm, sr = decode_clip(samples[0])
     assert sr == 16000 and pcm.dtype == np.int16 and np.array_equal(pcm, x) and pcm.flags.writeable
-    with pytest.raises(ValueError, match="FLAC"):
-        decode_clip(samples[1])
+    pcm, sr = decode_clip(samples[1])                       # flac member: the library's decoder
+    assert sr == 16000 and pcm.dtype == np.int16 and np.array_equal(pcm, x[::-1]) and pcm.flags.writeable
     with pytest.raises(ValueError, match="no audio"):
         decode_clip(samples[2])
+    with pytest.raises(RuntimeError, match="FLAC"):
+        decode_clip(samples[3])
 
 
 def test_fast_wav_reader_matches_scipy(tmp_path):

@@ -35,6 +35,8 @@ def main() -> None:
     ap.add_argument("--chunk", type=float, default=10.0)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--prefetch", type=int, default=4)
+    ap.add_argument("--format", default="wav", choices=["wav", "flac"], help="container of the generated files (flac: encoded by "
+                    "the test encoder of oracle/flac_codec.py, decoded by the library's vtc_flac_decode on the reader threads)")
     ap.add_argument("--no_group", action="store_true", help="one forward per file (A/B against cross-file batching)")
     ap.add_argument("--dir", default=None, help="scratch directory (default: a fresh temp dir, /dev/shm if present)")
     args = ap.parse_args()
@@ -45,9 +47,15 @@ def main() -> None:
     t0 = time.time()
     sigs = [synth.synth_audio(args.seconds, seed=1000 + i) for i in range(min(args.distinct, args.files))]
     paths = []
+    if args.format == "flac":
+        from oracle import flac_codec           # a tool may use the test encoder to make inputs; the product never does
+        blobs = [flac_codec.encode(np.clip(np.round(s * 32768.0), -32768, 32767).astype(np.int64), 16000) for s in sigs]
     for i in range(args.files):
-        p = root / "audio" / f"f{i:05d}.wav"
-        write_wav(p, sigs[i % len(sigs)])
+        p = root / "audio" / f"f{i:05d}.{args.format}"
+        if args.format == "flac":
+            p.write_bytes(blobs[i % len(blobs)])
+        else:
+            write_wav(p, sigs[i % len(sigs)])
         paths.append(p)
     (root / "manifests" / "c2.csv").write_text("path\n" + "\n".join(str(p) for p in paths) + "\n")
     (root / "cfg.yml").write_text(f"model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: {args.chunk}\n")
@@ -76,7 +84,7 @@ def main() -> None:
                       "note": "value includes model construction + weight packing (once per process); steady_state_value is "
                               "the CLI's own file loop + parquet writes", "files": args.files, "file_seconds": args.seconds,
                       "audio_hours": hours, "wall_s": wall, "raw_segments": n_raw, "generate_s": gen_s,
-                      "chunk_duration_s": args.chunk, "batch": args.batch, "prefetch": args.prefetch, "no_group": args.no_group}), flush=True)
+                      "chunk_duration_s": args.chunk, "batch": args.batch, "prefetch": args.prefetch, "no_group": args.no_group, "format": args.format}), flush=True)
     if not args.dir:
         import shutil
         shutil.rmtree(root, ignore_errors=True)

@@ -34,7 +34,7 @@ import pyarrow.compute as pc
 import pyarrow.parquet as pq
 import torch
 
-from ..audio import to_float32
+from ..audio import decode_flac, to_float32
 from ..core.intervals import intervals_to_segments
 from ..engine import RF_SIZE
 from ..segma_compat.config import load_config
@@ -75,18 +75,18 @@ def iter_tar_samples(tar_path):
 
 
 def decode_clip(sample):
-    """Audio member of a sample -> (pcm int16/float32 (n,) or (n, ch), sample_rate).  wav is preferred here because no
-    FLAC decoder is available offline; the reference prefers flac, its packer writes wav by default
-    (src/pipeline/package.py:152)."""
-    from scipy.io import wavfile
-
+    """Audio member of a sample -> (pcm int16/float32 (n,) or (n, ch), sample_rate).  flac is preferred, wav is the
+    fall-back, as in the reference (src/analysis/vtc_on_clips.py:163-169); flac goes through the library's own decoder
+    (vtc_flac_decode), straight from the tar member's bytes."""
+    if "flac" in sample:
+        return decode_flac(sample["flac"])
     if "wav" in sample:
+        from scipy.io import wavfile
+
         sr, data = wavfile.read(io.BytesIO(sample["wav"]))
         if data.dtype not in (np.int16, np.float32):
             data = to_float32(np.asarray(data))
         return np.array(data, order="C"), int(sr)          # own, writable copy (torch.from_numpy)
-    if "flac" in sample:
-        raise ValueError("flac clip: no FLAC decoder in this build (package with --audio_fmt wav)")
     raise ValueError("no audio found in sample")
 
 

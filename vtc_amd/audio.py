@@ -1,9 +1,11 @@
 """Audio front-end of the hot path: file -> mono 16 kHz float32 in [-1, 1).
 
 The reference leaves decoding to segma (torchaudio/torchcodec, requirements.txt:393-394); the rule for
-non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float)
-through scipy with mmap; channels are averaged; other rates are resampled with torchaudio's windowed-sinc
-polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
+non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float; own RIFF
+parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
+other rates are resampled with torchaudio's windowed-sinc polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
+The lossy formats of scripts/make_manifest.py:26-39 (mp3, ogg, opus, m4a, aac, wma) need codecs that are not available
+offline; they raise, which the pipeline turns into an error row.
 
 Two routes give the same samples: `read_pcm` + `VtcEngine.prepare_audio` (raw PCM is copied to the GPU and
 mixed / resampled there: the pipeline's route) and `read_audio` (all on the host: tests, small tools).
@@ -78,12 +80,121 @@ def _fast_wav(path: Path):
                 f.seek(size + (size & 1), 1)
 
 
+def decode_flac(data, verify_md5: bool = False):
+    """FLAC stream held in memory (bytes, bytearray, or a uint8 array / memmap) -> (samples, sample_rate); samples are
+    int16 as stored for 16-bit streams (the common case: half the PCIe bytes of float), else float32 = integer /
+    2^(bits-1); shape (n,) or (n, channels).  Frame CRCs are always checked; verify_md5 also checks STREAMINFO's MD5
+    of the decoded integers.  Runs in libvtc_amd.so outside the GIL."""
+    import ctypes as C
+
+    from . import lib as L
+
+    lib = L.load()
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
+    ptr, nbytes = C.c_void_p(buf.ctypes.data), C.c_int64(buf.size)
+    sr, ch, bps, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    md5 = (C.c_uint8 * 16)()
+    L.check(lib.vtc_flac_info(ptr, nbytes, C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total), md5))
+    n = total.value
+    got = C.c_int64()
+    if n == 0:                                       # length not declared: count first
+        L.check(lib.vtc_flac_decode(ptr, nbytes, None, 2, 0, C.byref(got)))
+        n = got.value
+    want_md5 = verify_md5 and any(md5)
+    if bps.value == 16:
+        fmt, dtype = 0, np.int16
+    elif want_md5:
+        fmt, dtype = 2, np.int32
+    else:
+        fmt, dtype = 1, np.float32
+    out = np.empty((n, ch.value), dtype=dtype)
+    L.check(lib.vtc_flac_decode(ptr, nbytes, C.c_void_p(out.ctypes.data), fmt, n, C.byref(got)))
+    out = out[:got.value]
+    if want_md5:
+        import hashlib
+
+        width = (bps.value + 7) // 8
+        raw = out.tobytes() if width == out.itemsize else \
+            np.ascontiguousarray(out.astype("<i4")).view(np.uint8).reshape(-1, 4)[:, :width].tobytes()
+        if hashlib.md5(raw).digest() != bytes(md5):
+            raise ValueError("FLAC: MD5 of the decoded samples differs from the stream's STREAMINFO")
+        if fmt == 2:
+            out = (out.astype(np.float64) / float(1 << (bps.value - 1))).astype(np.float32)
+    return (out[:, 0] if ch.value == 1 else out), int(sr.value)
+
+
+def decode_aiff(data):
+    """AIFF / AIFF-C with uncompressed PCM ('NONE', 'twos', 'sowt', 'fl32'/'FL32') -> (samples, sample_rate)."""
+    import struct
+
+    buf = memoryview(data)
+    if len(buf) < 12 or bytes(buf[:4]) != b"FORM" or bytes(buf[8:12]) not in (b"AIFF", b"AIFC"):
+        raise ValueError("not an AIFF file")
+    aifc = bytes(buf[8:12]) == b"AIFC"
+    o, comm, ssnd = 12, None, None
+    while o + 8 <= len(buf):
+        cid, size = bytes(buf[o:o + 4]), struct.unpack(">I", buf[o + 4:o + 8])[0]
+        body = o + 8
+        if cid == b"COMM":
+            ch, nframes, bits = struct.unpack(">hIh", buf[body:body + 8])
+            expo, mant = struct.unpack(">HQ", buf[body + 8:body + 18])      # 80-bit extended sample rate
+            rate = (mant / float(1 << 63)) * 2.0 ** ((expo & 0x7FFF) - 16383) if mant else 0.0
+            ctype = bytes(buf[body + 18:body + 22]) if aifc and size >= 22 else b"NONE"
+            comm = (ch, nframes, bits, int(round(rate)), ctype)
+        elif cid == b"SSND":
+            offset = struct.unpack(">I", buf[body:body + 4])[0]
+            ssnd = (body + 8 + offset, min(size - 8 - offset, len(buf) - body - 8 - offset))
+        o = body + size + (size & 1)
+    if comm is None or ssnd is None:
+        raise ValueError("AIFF file without COMM or SSND chunk")
+    ch, nframes, bits, rate, ctype = comm
+    start, nbytes = ssnd
+    width = (bits + 7) // 8
+    n = min(nframes, nbytes // (width * ch)) if ch > 0 and width > 0 else 0
+    raw = np.frombuffer(buf, dtype=np.uint8, count=n * ch * width, offset=start)
+    if ctype in (b"fl32", b"FL32"):
+        x = raw.view(">f4").astype(np.float32)
+    elif ctype in (b"NONE", b"twos", b"sowt"):
+        order = "<" if ctype == b"sowt" else ">"
+        if width == 2:
+            x = raw.view(order + "i2").astype(np.int16)
+        elif width == 1:
+            x = raw.view(np.int8).astype(np.float32) / np.float32(128.0)
+        elif width == 4:
+            x = (raw.view(order + "i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif width == 3:
+            b = raw.reshape(-1, 3).astype(np.int32)
+            hi, mid, lo = (b[:, 0], b[:, 1], b[:, 2]) if order == ">" else (b[:, 2], b[:, 1], b[:, 0])
+            v = (hi << 16) | (mid << 8) | lo
+            v = np.where(v >= (1 << 23), v - (1 << 24), v)
+            x = (v.astype(np.float64) / float(1 << 23)).astype(np.float32)
+        else:
+            raise ValueError(f"AIFF: unsupported sample size {bits}")
+    else:
+        raise ValueError(f"AIFF-C compression {ctype!r} is not supported")
+    return (x.reshape(n, ch) if ch > 1 else x), rate
+
+
+def _file_bytes(path: Path):
+    size = path.stat().st_size
+    return np.memmap(path, dtype=np.uint8, mode="r") if size >= (8 << 20) else np.fromfile(path, dtype=np.uint8)
+
+
+UNSUPPORTED_LOSSY = (".mp3", ".ogg", ".opus", ".m4a", ".aac", ".wma")
+
+
 def read_pcm(path):
     """Decode only as far as the container: (samples, sample_rate) with samples int16 or float32, shape (n,) or
     (n, channels), memory-mapped when large.  Mixing and resampling are left to the GPU."""
     path = Path(path)
-    if path.suffix.lower() not in (".wav", ".wave"):
-        raise ValueError(f"{path.name}: only WAV input is supported by this build (got '{path.suffix}')")
+    ext = path.suffix.lower()
+    if ext == ".flac":
+        return decode_flac(_file_bytes(path))
+    if ext in (".aiff", ".aif", ".aifc"):
+        return decode_aiff(_file_bytes(path))
+    if ext not in (".wav", ".wave"):
+        why = "needs a codec that is not available in this build" if ext in UNSUPPORTED_LOSSY else "unknown audio format"
+        raise ValueError(f"{path.name}: '{ext}' {why} (supported: wav, flac, aiff)")
     fast = _fast_wav(path)
     if fast is not None:
         return fast
@@ -139,11 +250,12 @@ def read_audio(path) -> np.ndarray:
 
     path = Path(path)
     if path.suffix.lower() not in (".wav", ".wave"):
-        raise ValueError(f"{path.name}: only WAV input is supported by this build (got '{path.suffix}')")
-    try:
-        sr, data = wavfile.read(str(path), mmap=True)
-    except ValueError:
-        sr, data = wavfile.read(str(path), mmap=False)   # 24-bit PCM cannot be memory-mapped
+        data, sr = read_pcm(path)
+    else:
+        try:
+            sr, data = wavfile.read(str(path), mmap=True)
+        except ValueError:
+            sr, data = wavfile.read(str(path), mmap=False)   # 24-bit PCM cannot be memory-mapped
     x = to_float32(np.asarray(data))
     if x.ndim == 2:
         x = x.mean(axis=1, dtype=np.float32)

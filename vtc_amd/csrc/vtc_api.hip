@@ -18,6 +18,7 @@
 #include "common.cuh"
 #include "decode_kernels.cuh"
 #include "encoder_kernels.cuh"
+#include "flac_decode.h"
 #include "gemm.cuh"
 #include "gemm256.cuh"
 #include "posconv.cuh"
@@ -877,6 +878,33 @@ int vtc_prepare_audio(vtc_model* m, const void* pcm, int32_t format, int64_t n_i
     LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
                                                          (long long)n_in, n_channels, t, out, (long long)need));
   HIP_TRY(m, hipGetLastError());
+  return VTC_OK;
+}
+
+// ---- host-side FLAC front-end (no device work, no handle; errors go to vtc_last_error(NULL) of the calling thread)
+int vtc_flac_info(const void* data, int64_t n_bytes, int32_t* sample_rate, int32_t* n_channels, int32_t* bits_per_sample,
+                  int64_t* n_samples, uint8_t* md5) {
+  if (!data || n_bytes < 0) return fail(nullptr, VTC_ERR_ARG, "null argument");
+  flac::StreamInfo si;
+  flac::Error err;
+  if (!flac::parse_header((const uint8_t*)data, n_bytes, si, err)) return fail(nullptr, VTC_ERR_ARG, "%s", err.msg.c_str());
+  if (sample_rate) *sample_rate = si.sample_rate;
+  if (n_channels) *n_channels = si.channels;
+  if (bits_per_sample) *bits_per_sample = si.bps;
+  if (n_samples) *n_samples = si.total;
+  if (md5) memcpy(md5, si.md5, 16);
+  return VTC_OK;
+}
+
+int vtc_flac_decode(const void* data, int64_t n_bytes, void* out, int32_t out_format, int64_t out_cap, int64_t* n_out) {
+  if (!data || n_bytes < 0 || !n_out) return fail(nullptr, VTC_ERR_ARG, "null argument");
+  if (out_format < 0 || out_format > 2) return fail(nullptr, VTC_ERR_ARG, "out_format must be 0 (int16), 1 (float32) or 2 (int32)");
+  flac::StreamInfo si;
+  flac::Error err;
+  const int64_t got = flac::decode((const uint8_t*)data, n_bytes, out, out_format, out_cap, si, err);
+  if (got == -2) return fail(nullptr, VTC_ERR_CAPACITY, "%s", err.msg.c_str());
+  if (got < 0) return fail(nullptr, VTC_ERR_ARG, "%s", err.msg.c_str());
+  *n_out = got;
   return VTC_OK;
 }
 
