@@ -687,6 +687,71 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
     assert pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist() == rows
 
 
+def test_grid_cut_clips_reproduce_full_file_rows_and_align(weights, tmp_path, monkeypatch):
+    """Clip-grid rule (src/packaging/clips.py:48-61) + the alignment consumer (src/pipeline/vtc_clip_alignment.py): a clip
+    cut at a multiple of the window step re-creates the full-file windows, so its logits ARE the full-file rows (bit for
+    bit); run through both CLIs (full files; FLAC clips in tars) the raw segments cover exactly the same time."""
+    import io, tarfile
+    import pyarrow as pa
+    from oracle import flac_codec as FL
+    from vtc_amd.analysis import vtc_on_clips as clips
+    from vtc_amd.packaging.clips import CHUNK_STEP_F, snap_to_grid
+    from vtc_amd.pipeline import vtc as cli, vtc_clip_alignment as A
+    monkeypatch.chdir(tmp_path)
+    step, T = CHUNK_STEP_F, 199
+    n = 15 * step + 320
+    dur = n / 16000.0
+    cuts = [0.0] + [snap_to_grid(t, dur) for t in (20.0, 41.5)] + [dur]
+    assert [round(c * 16000) for c in cuts[1:3]] == [5 * step, 10 * step]
+    eng = _engine(weights, 4.0, 8)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    shard_dir = tmp_path / "output" / "g" / "shards"
+    shard_dir.mkdir(parents=True)
+    stats, names = {"clip_id": [], "uid": [], "abs_onset": []}, []
+    with tarfile.open(shard_dir / "shards-0000.tar", "w") as tf:
+        for r in range(2):
+            x = synth.synth_audio(dur + 0.1, seed=500 + r)[:n]
+            pcm = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+            (tmp_path / "audio" / f"rec{r}.flac").write_bytes(FL.encode(pcm.astype(np.int64), 16000))
+            names.append(str(tmp_path / "audio" / f"rec{r}.flac"))
+            wav = torch.from_numpy(O.pcm_to_mono_float(pcm)).cuda()
+            full = eng.infer_waveform(wav, batch_size=8)
+            for k in range(3):
+                a, b = round(cuts[k] * 16000), min(round(cuts[k + 1] * 16000) + 320, n)   # + the last frame's receptive field
+                part = eng.infer_waveform(wav[a:b].contiguous(), batch_size=8)
+                rows = (b - a - 320) // step * T
+                assert part.shape[0] == rows and torch.equal(part, full[a // 320: a // 320 + rows]), (r, k)
+                blob = FL.encode(pcm[a:b].astype(np.int64), 16000)
+                info = tarfile.TarInfo(f"rec{r}_{k:04d}.flac")
+                info.size = len(blob)
+                tf.addfile(info, io.BytesIO(blob))
+                stats["clip_id"].append(f"rec{r}_{k:04d}")
+                stats["uid"].append(f"rec{r}")
+                stats["abs_onset"].append(a / 16000.0)
+    eng.close()
+    (tmp_path / "manifests" / "g.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    common = dict(config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8)
+    cli.main("g", **common)
+    clips.main("g", **common)
+    out = tmp_path / "output" / "g"
+    (out / "stats").mkdir()
+    pq.write_table(pa.table(stats), out / "stats" / "clip_stats.parquet")
+    full_raw = pq.read_table(out / "vtc_raw" / "shard_0.parquet")
+    clip_raw = A._to_absolute(pq.read_table(out / "vtc_clips" / "vtc_raw" / "shard_0.parquet"), pa.table(stats))
+    assert full_raw.num_rows > 20
+    cov = A.compute_coverage(full_raw, clip_raw)
+    for k, c in cov.items():                              # raw runs: same active frames -> same covered time
+        assert c["only_full_h"] * 3600 < 1e-6 and c["only_clip_h"] * 3600 < 1e-6, (k, c)
+    assert cov["all_speech"]["both_h"] * 3600 > 5.0
+    A.main("g")                                           # merged tables: only collar effects at the cuts may differ
+    rows = {r["label"]: r for r in __import__("csv").DictReader(open(out / "vtc_clip_alignment_coverage.csv"))}
+    assert float(rows["all_speech"]["agreement_pct"]) >= 95.0, rows["all_speech"]
+    m = {r["label"]: r for r in __import__("csv").DictReader(open(out / "vtc_clip_alignment_matches.csv"))}
+    assert sum(int(r["n_matched"]) for r in m.values()) > 0
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)
