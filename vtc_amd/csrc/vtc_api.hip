@@ -618,9 +618,12 @@ static int decode_impl(vtc_model* m, const float* logits, int64_t n, const float
     const int c = totals[l];
     runs_start[l].resize(c); runs_end[l].resize(c);
     if (!c) continue;
-    HIP_TRY(m, hipMemcpy(runs_start[l].data(), m->dec_start + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
-    HIP_TRY(m, hipMemcpy(runs_end[l].data(), m->dec_end + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost));
+    // on the caller's stream, never the null stream: a caller that has already queued the next forward on another
+    // stream must not wait for it here
+    HIP_TRY(m, hipMemcpyAsync(runs_start[l].data(), m->dec_start + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost, s));
+    HIP_TRY(m, hipMemcpyAsync(runs_end[l].data(), m->dec_end + (long long)l * dcap, sizeof(int) * c, hipMemcpyDeviceToHost, s));
   }
+  HIP_TRY(m, hipStreamSynchronize(s));
   return VTC_OK;
 }
 
@@ -722,7 +725,8 @@ int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows
   if (int rc = decode_impl(m, logits, n, lo, hi, m->dec_fstart, rs, re, nullptr, nullptr, s)) return rc;   // synchronises s
   if (max_logit || mean_sigmoid) {
     std::vector<double> hsum((size_t)2 * n_files);
-    HIP_TRY(m, hipMemcpy(hsum.data(), m->fsum_out, sizeof(double) * 2 * n_files, hipMemcpyDeviceToHost));
+    HIP_TRY(m, hipMemcpyAsync(hsum.data(), m->fsum_out, sizeof(double) * 2 * n_files, hipMemcpyDeviceToHost, s));
+    HIP_TRY(m, hipStreamSynchronize(s));
     for (int f = 0; f < n_files; ++f) {
       const long long cnt = (file_rows[f + 1] - file_rows[f]) * nl;
       if (max_logit) max_logit[f] = cnt ? (float)hsum[2 * f + 1] : -INFINITY;

@@ -123,31 +123,55 @@ def stage_audio(path, engine) -> torch.Tensor:
 def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logits: bool):
     """GPU-thread stage: forward + threshold/run-length decode; only the decoded triples (and, on request, the
     logits) come back to the host."""
-    gpu_wav.record_stream(torch.cuda.current_stream(engine.device))
-    with torch.no_grad():
-        logits = engine.infer_waveform(gpu_wav, batch_size)
-        starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
-        cpu_logits = logits.cpu() if want_logits else None
-    return starts, ends, lab, max_logit, mean_sig, int(gpu_wav.numel()), cpu_logits
+    return gpu_collect(engine, gpu_launch(engine, [gpu_wav], batch_size, grouped=False), lo, hi, want_logits)[0]
 
 
 def gpu_group_stage(engine, wavs, lo, hi, batch_size: int, want_logits: bool):
     """GPU-thread stage for several short recordings: their windows share forward passes (vtc_infer_waveforms) and one
     segmented decode with per-recording sigmoid summaries (vtc_decode_files).  Returns one gpu_stage-shaped tuple per
     recording.  A 30 s file is 8 windows of 4 s: alone it would use 1/16 of a 128-window batch."""
+    return gpu_collect(engine, gpu_launch(engine, wavs, batch_size, grouped=True), lo, hi, want_logits)
+
+
+def gpu_launch(engine, wavs, batch_size: int, grouped: bool):
+    """First half of the GPU stage: enqueue the forward passes on the current stream and return without waiting.
+    The decode (which ends in a host synchronisation) is the second half, gpu_collect, so that the GPU thread can
+    enqueue the NEXT forward before it blocks on this one: the GPU never waits for Python between recordings."""
     cur = torch.cuda.current_stream(engine.device)
     for w in wavs:
         w.record_stream(cur)
     with torch.no_grad():
-        logits, rows = engine.infer_waveforms(wavs, batch_size)
+        if grouped:
+            logits, rows = engine.infer_waveforms(wavs, batch_size)
+        else:
+            logits, rows = engine.infer_waveform(wavs[0], batch_size), None
+    done = torch.cuda.Event()
+    done.record(cur)
+    return logits, rows, done, [int(w.numel()) for w in wavs]
+
+
+def gpu_collect(engine, launched, lo, hi, want_logits: bool):
+    """Second half: threshold + run-length decode on a side stream that waits for the forward's event (a forward
+    enqueued in between keeps running underneath), then the small D2H copies.  One gpu_stage-shaped tuple per recording."""
+    logits, rows, done, n_samples = launched
+    side = getattr(_TLS, "decode_stream", None)
+    if side is None:
+        side = _TLS.decode_stream = torch.cuda.Stream(engine.device)
+    side.wait_event(done)
+    logits.record_stream(side)
+    with torch.no_grad(), torch.cuda.stream(side):
+        if rows is None:
+            starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
+            cpu_logits = logits.cpu() if want_logits else None
+            return [(starts, ends, lab, max_logit, mean_sig, n_samples[0], cpu_logits)]
         fidx, starts, ends, lab, mx, mean = engine.decode_files(logits, rows, lo, hi, summary=True)
-        bounds = np.searchsorted(fidx, np.arange(len(wavs) + 1))      # fidx is sorted (recording-major output)
+        bounds = np.searchsorted(fidx, np.arange(len(n_samples) + 1))      # fidx is sorted (recording-major output)
         out = []
-        for f, w in enumerate(wavs):
+        for f, n in enumerate(n_samples):
             a, b = int(bounds[f]), int(bounds[f + 1])
             cpu_logits = logits[int(rows[f]):int(rows[f + 1])].cpu() if want_logits else None
-            out.append((starts[a:b], ends[a:b], lab[a:b], float(mx[f]), float(mean[f]), int(w.numel()), cpu_logits))
-    return out
+            out.append((starts[a:b], ends[a:b], lab[a:b], float(mx[f]), float(mean[f]), n, cpu_logits))
+        return out
 
 
 def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
@@ -327,29 +351,51 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 inflight_bytes += sizes.get(todo[nxt], 0)
                 nxt += 1
 
+        pending = None     # (items, launched): forward enqueued, decode not collected yet
+        serial_gpu = os.environ.get("VTC_SERIAL_GPU_STAGE") == "1"    # diagnostic: collect right after launching (A/B timing)
+
+        def drain():
+            """Collect the batch whose forward is in flight (decode + host sync) and publish its results."""
+            nonlocal pending
+            if pending is None:
+                return
+            (items, launched), pending = pending, None
+            try:
+                outs = gpu_collect(engine, launched, lo, hi, save_logits)
+                for (i, _), o in zip(items, outs):
+                    results[i].set_result(o)
+            except Exception as e:
+                redo(items, e)
+
+        def redo(items, e):
+            if len(items) == 1:
+                results[items[0][0]].set_exception(e)
+                return
+            for i, w in items:       # one bad recording must not take its batch mates down: redo them one by one
+                try:
+                    results[i].set_result(gpu_stage(engine, w, lo, hi, batch_size, save_logits))
+                except Exception as e1:
+                    results[i].set_exception(e1)
+
         def run_group():
-            nonlocal group, group_windows
+            """Enqueue the forward of the current group, THEN collect the previous one: its decode and host
+            synchronisation overlap the forward that was just enqueued."""
+            nonlocal group, group_windows, pending
             if not group:
                 return
             items, group, group_windows = group, [], 0
             t_run = time.perf_counter()
             try:
-                if len(items) == 1:
-                    outs = [gpu_stage(engine, items[0][1], lo, hi, batch_size, save_logits)]
-                else:
-                    outs = gpu_group_stage(engine, [w for _, w in items], lo, hi, batch_size, save_logits)
-                for (i, _), o in zip(items, outs):
-                    results[i].set_result(o)
-                _tick("gpu_run", t_run)
+                launched = gpu_launch(engine, [w for _, w in items], batch_size, grouped=len(items) > 1)
             except Exception as e:
-                if len(items) == 1:
-                    results[items[0][0]].set_exception(e)
-                    return
-                for i, w in items:       # one bad recording must not take its batch mates down: redo them one by one
-                    try:
-                        results[i].set_result(gpu_stage(engine, w, lo, hi, batch_size, save_logits))
-                    except Exception as e1:
-                        results[i].set_exception(e1)
+                drain()
+                redo(items, e)
+                return
+            drain()
+            pending = (items, launched)
+            if serial_gpu:
+                drain()
+            _tick("gpu_run", t_run)
 
         try:
             top_up()
@@ -357,8 +403,11 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 i, fut = inflight.popleft()
                 inflight_bytes -= sizes.get(todo[i], 0)
                 top_up()
-                if group and not fut.done():
+                if not fut.done():
                     run_group()          # the next recording is not staged yet: do not hold a partial batch back
+                    t_run = time.perf_counter()
+                    drain()              # ... and publish what is in flight instead of sitting on it while waiting
+                    _tick("gpu_run", t_run)
                 t_wait = time.perf_counter()
                 try:
                     wav = fut.result()
@@ -380,6 +429,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 if group_windows >= batch_size:
                     run_group()
             run_group()
+            drain()
         except BaseException as e:       # never leave the consumer waiting on a future that will not resolve
             for f in results:
                 if not f.done():
