@@ -396,3 +396,43 @@ def test_fast_wav_reader_matches_scipy(tmp_path):
     (tmp_path / "junk.wav").write_bytes(b"not a wav file at all")
     with pytest.raises(Exception):
         audio.read_pcm(tmp_path / "junk.wav")
+
+
+def test_columnar_segments_and_meta_equal_the_scalar_forms():
+    """The CLI gathers segments as column blocks (core.intervals.intervals_to_columns, metadata.vtc_meta_row_columns,
+    utils.segments_table_from_blocks); they must give exactly the rows of the scalar mirror of the reference
+    (intervals_to_segments / vtc_meta_row / segments_table): same doubles, same JSON, same table."""
+    from vtc_amd.core.intervals import intervals_to_columns, intervals_to_segments
+    from vtc_amd.core.metadata import vtc_meta_row, vtc_meta_row_columns
+    rng = np.random.default_rng(3)
+    labels = ["KCHI", "OCH", "MAL", "FEM"]
+    # every frame index of a 16 h file is a possible bound: sample them densely at both ends and at random in between
+    i = np.unique(np.concatenate([np.arange(0, 60000), rng.integers(0, 2_880_000, 200_000), np.arange(2_870_000, 2_880_000)]))
+    starts = i * 320
+    ends = (i + rng.integers(0, 400, size=len(i))) * 320 + 400
+    on, off, dur, keep = intervals_to_columns(starts, ends)
+    assert keep.all()
+    for k in rng.integers(0, len(i), 20000).tolist() + list(range(3000)):
+        a, b = round(int(starts[k]) / 16000, 3), round(int(ends[k]) / 16000, 3)
+        assert on[k] == a and off[k] == b and dur[k] == round(b - a, 3), k
+    # a degenerate interval (end <= start) is dropped by both forms
+    _, _, _, kp = intervals_to_columns([320, 640], [320, 640 + 400])
+    assert list(kp) == [False, True]
+    assert intervals_to_segments([(320, 320, "FEM")], "u") == []
+    # whole files: rows, meta row and table
+    blocks, rows_all = [], []
+    for f in range(6):
+        n = [0, 1, 7, 300, 2500, 40][f]
+        lab = np.sort(rng.integers(0, 4, n)) if f != 4 else rng.integers(0, 4, n)      # decoder order is label-major
+        s = rng.integers(0, 100000, n) * 320
+        e = s + rng.integers(0, 300, n) * 320 + 400
+        segs = intervals_to_segments([(int(a), int(b), labels[int(c)]) for a, b, c in zip(s, e, lab)], f"file{f}")
+        o1, o2, d, kp = intervals_to_columns(s, e)
+        block = (f"file{f}", o1[kp], o2[kp], d[kp], lab[kp].astype(np.int32))
+        assert vtc_meta_row_columns(f"file{f}", 0.5, block[3], block[4], labels, 0.9, 0.1) == vtc_meta_row(f"file{f}", 0.5, segs, 0.9, 0.1)
+        blocks.append(block)
+        rows_all.extend(segs)
+    got = utils.segments_table_from_blocks(blocks, labels)
+    assert got.equals(utils.segments_table(rows_all)) and got.schema == utils.SEGMENT_SCHEMA
+    assert utils.segments_table_from_blocks([], labels).num_rows == 0
+    assert utils.segments_table_from_blocks(blocks[:1], labels).num_rows == 0

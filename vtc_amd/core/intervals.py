@@ -7,6 +7,8 @@ rows with non-positive duration dropped.
 
 from __future__ import annotations
 
+import numpy as np
+
 from ..segma_compat.utils.conversions import frames_to_seconds
 
 
@@ -45,3 +47,14 @@ def intervals_to_segments(intervals, uid: str) -> list[dict]:
             continue
         segments.append({"uid": uid, "onset": onset, "offset": offset, "duration": duration, "label": label})
     return segments
+
+
+def intervals_to_columns(starts, ends):
+    """Array form of intervals_to_segments for the decoder's output (sample indices): (onset, offset, duration, keep)
+    as float64 arrays and the duration > 0 mask.  Decoder bounds are whole frames (start = 320 i, end = 320 j + 400),
+    i.e. exact 3-decimal numbers of seconds, for which rint(x * 1000) / 1000 is the same double as Python's
+    round(x, 3); tests/test_host.py checks the equality against the scalar form."""
+    onset = np.rint(np.asarray(starts, dtype=np.float64) / 16000.0 * 1000.0) / 1000.0
+    offset = np.rint(np.asarray(ends, dtype=np.float64) / 16000.0 * 1000.0) / 1000.0
+    duration = np.rint((offset - onset) * 1000.0) / 1000.0
+    return onset, offset, duration, duration > 0

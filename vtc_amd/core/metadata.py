@@ -30,3 +30,23 @@ def vtc_meta_row(uid: str, threshold: float, segments: list, max_sigmoid: float,
         "vtc_n_segments": len(segments), "vtc_label_counts": json.dumps(per_label),
         "vtc_max_sigmoid": max_sigmoid, "vtc_mean_sigmoid": mean_sigmoid, "error": "",
     }
+
+
+def vtc_meta_row_columns(uid: str, threshold: float, durations, label_codes, labels, max_sigmoid: float,
+                         mean_sigmoid: float) -> dict:
+    """vtc_meta_row from column arrays (durations float64, label_codes int, in segment order): the same left-to-right
+    sum of durations and the same first-appearance order of the labels in the JSON."""
+    import numpy as np
+
+    n = int(len(durations))
+    total = float(np.cumsum(np.asarray(durations, dtype=np.float64))[-1]) if n else 0.0   # cumsum adds sequentially
+    per_label: dict = {}
+    if n:
+        codes, first, counts = np.unique(np.asarray(label_codes), return_index=True, return_counts=True)
+        for k in np.argsort(first, kind="stable"):
+            per_label[labels[int(codes[k])]] = int(counts[k])
+    return {
+        "uid": uid, "vtc_threshold": threshold, "vtc_speech_dur": round(total, 3),
+        "vtc_n_segments": n, "vtc_label_counts": json.dumps(per_label),
+        "vtc_max_sigmoid": max_sigmoid, "vtc_mean_sigmoid": mean_sigmoid, "error": "",
+    }

@@ -38,8 +38,8 @@ import pyarrow.parquet as pq
 import torch
 
 from ..audio import read_pcm
-from ..core.intervals import intervals_to_segments
-from ..core.metadata import vtc_error_row, vtc_meta_row
+from ..core.intervals import intervals_to_columns
+from ..core.metadata import vtc_error_row, vtc_meta_row_columns
 from ..engine import RF_SIZE
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
@@ -48,13 +48,13 @@ from ..segma_compat.models import Models
 from ..segma_compat.utils.encoders import MultiLabelEncoder
 from ..utils import (SEGMENT_SCHEMA, add_sample_argument, atomic_write_parquet, get_dataset_paths, hhmmss,
                      balanced_shards, load_completed_ids, load_manifest, log_benchmark, manifest_paths, merge_segments, meta_table,
-                     sample_manifest, segments_table, set_seeds, shard_list)
+                     sample_manifest, segments_table_from_blocks, set_seeds, shard_list)
 
 logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
 logger = logging.getLogger("vtc")
 
 _TLS = threading.local()
-STAGE_SECONDS = {"read": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0, "finish": 0.0}   # summed wall time per stage (logged at the end)
+STAGE_SECONDS = {"read": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0, "gpu_launch": 0.0, "gpu_collect": 0.0, "finish": 0.0}   # summed wall time per stage (logged at the end)
 _TIMER_LOCK = threading.Lock()
 
 
@@ -175,14 +175,26 @@ def gpu_collect(engine, launched, lo, hi, want_logits: bool):
 
 
 def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
-    """Host stage: triples -> segment rows + meta row (reference vtc.py:252-281)."""
+    """Host stage: decoded runs -> the file's segment columns + meta row (reference vtc.py:252-281).  Columns, not one
+    dict per segment: a block is (uid, onset, offset, duration, label_codes) with numpy arrays, joined into the shard's
+    table by utils.segments_table_from_blocks; same values as core.intervals.intervals_to_segments / vtc_meta_row."""
     starts, ends, lab, max_logit, mean_sig, _, cpu_logits = decoded
     if save_to is not None:
         torch.save({labels[j]: cpu_logits[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
-    intervals = [(int(s), int(e), labels[int(k)]) for s, e, k in zip(starts, ends, lab)]
-    segs = intervals_to_segments(intervals, uid)
+    onset, offset, duration, keep = intervals_to_columns(starts, ends)
+    codes = np.asarray(lab, dtype=np.int32)
+    if not keep.all():
+        onset, offset, duration, codes = onset[keep], offset[keep], duration[keep], codes[keep]
     max_sig = round(float(torch.sigmoid(torch.tensor(max_logit, dtype=torch.float32)).item()), 4)
-    return segs, vtc_meta_row(uid, threshold, segs, max_sig, round(float(mean_sig), 4))
+    row = vtc_meta_row_columns(uid, threshold, duration, codes, labels, max_sig, round(float(mean_sig), 4))
+    return (uid, onset, offset, duration, codes), row
+
+
+def block_rows(block, labels) -> list[dict]:
+    """A segment block as the reference's list of dicts (tests, small tools)."""
+    uid, onset, offset, duration, codes = block
+    return [{"uid": uid, "onset": float(a), "offset": float(b), "duration": float(d), "label": labels[int(k)]}
+            for a, b, d, k in zip(onset, offset, duration, codes)]
 
 
 def process_file(engine, wav: np.ndarray, uid: str, threshold: float, labels, batch_size: int, save_to: Path | None):
@@ -279,7 +291,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     total = len(todo)
     print(f"Shard {shard_id}: {total} files, {total_bytes / 1e9:.1f} GB", flush=True)
 
-    meta_rows, seg_rows = [], []
+    meta_rows, seg_blocks = [], []
     n_errors, bytes_done, audio_seconds = 0, 0, 0.0
     t0 = last_log = last_flush = time.time()
     since_flush = 0
@@ -305,9 +317,9 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         if final and meta_df.num_rows < before:
             logger.warning(f"Dedup: removed {before - meta_df.num_rows} duplicate meta rows (shard {shard_id})")
 
-        new_seg = segments_table(seg_rows)
+        new_seg = segments_table_from_blocks(seg_blocks, labels)
         if prev_seg_all is not None:
-            prev_seg = _drop_uids(prev_seg_all, {r["uid"] for r in seg_rows})
+            prev_seg = _drop_uids(prev_seg_all, {b[0] for b in seg_blocks})
             seg_df = pa.concat_tables([t for t in (prev_seg, new_seg) if t.num_rows]) if (prev_seg.num_rows or new_seg.num_rows) else new_seg
         else:
             seg_df = new_seg
@@ -360,12 +372,14 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             if pending is None:
                 return
             (items, launched), pending = pending, None
+            t_col = time.perf_counter()
             try:
                 outs = gpu_collect(engine, launched, lo, hi, save_logits)
                 for (i, _), o in zip(items, outs):
                     results[i].set_result(o)
             except Exception as e:
                 redo(items, e)
+            _tick("gpu_collect", t_col)
 
         def redo(items, e):
             if len(items) == 1:
@@ -391,6 +405,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 drain()
                 redo(items, e)
                 return
+            _tick("gpu_launch", t_run)
             drain()
             pending = (items, launched)
             if serial_gpu:
@@ -457,7 +472,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     logger.warning(f"{uid}: {e}")
                     meta_rows.append(vtc_error_row(uid, str(e)))
                     continue
-                seg_rows.extend(segs)
+                seg_blocks.append(segs)
                 meta_rows.append(row)
                 bytes_done += sizes.get(uid, 0)
                 now = time.time()
@@ -488,7 +503,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     logger.info(f"  Segments  : {seg_df.num_rows:,} raw, {merged_df.num_rows:,} merged")
     logger.info(f"  Wall time : {hhmmss(wall)}   ({audio_seconds / 3600.0 / max(wall, 1e-9):.3f} audio-hours/s)")
     logger.info("  Stage time: " + ", ".join(f"{k} {v:.2f}s" for k, v in STAGE_SECONDS.items()) +
-                f"  (read is summed over {depth} reader threads; wall {wall:.2f}s)")
+                f"  (read is summed over {depth} reader threads, gpu_run = gpu_launch + gpu_collect; wall {wall:.2f}s)")
     logger.info("-" * 50)
     done_bytes = sum(os.path.getsize(uid_to_path[u]) for u in todo if os.path.exists(uid_to_path[u]))
     log_benchmark(step="vtc", dataset=dataset, n_files=total, wall_seconds=wall, total_audio_seconds=audio_seconds,

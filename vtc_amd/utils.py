@@ -177,17 +177,15 @@ def merge_segments(table: pa.Table, min_duration_off_s: float = 0.1, min_duratio
     if table.num_rows == 0:
         return table
     has_label = "label" in table.column_names
-    uid = np.asarray(table.column("uid").to_pylist(), dtype=object)
-    lab = np.asarray(table.column("label").to_pylist(), dtype=object) if has_label else None
     onset = table.column("onset").to_numpy(zero_copy_only=False).astype(np.float64)
     offset = table.column("offset").to_numpy(zero_copy_only=False).astype(np.float64)
 
-    uid_names, uid_code = np.unique(uid.astype(str), return_inverse=True)
+    uid_names, uid_code = _sorted_codes(table.column("uid"))
     if has_label:
-        lab_names, lab_code = np.unique(lab.astype(str), return_inverse=True)
-        part = uid_code.astype(np.int64) * len(lab_names) + lab_code
+        lab_names, lab_code = _sorted_codes(table.column("label"))
+        part = uid_code * len(lab_names) + lab_code
     else:
-        part = uid_code.astype(np.int64)
+        part = uid_code
     order = np.lexsort((onset, part))           # stable: ties keep input order, like a stable sort
     part, onset, offset = part[order], onset[order], offset[order]
 
@@ -210,15 +208,40 @@ def merge_segments(table: pa.Table, min_duration_off_s: float = 0.1, min_duratio
     g_on, g_off, g_dur, g_part = g_on[keep], g_off[keep], g_dur[keep], g_part[keep]
     final = np.lexsort((g_on, g_part))
     g_on, g_off, g_dur, g_part = g_on[final], g_off[final], g_dur[final], g_part[final]
-    cols = {}
-    if has_label:
-        cols["uid"] = pa.array(uid_names[g_part // len(lab_names)].tolist(), pa.string())
-    else:
-        cols["uid"] = pa.array(uid_names[g_part].tolist(), pa.string())
+    cols = {"uid": _string_column(g_part // len(lab_names) if has_label else g_part, uid_names)}
     cols["onset"], cols["offset"], cols["duration"] = pa.array(g_on), pa.array(g_off), pa.array(g_dur)
     if has_label:
-        cols["label"] = pa.array(lab_names[g_part % len(lab_names)].tolist(), pa.string())
+        cols["label"] = _string_column(g_part % len(lab_names), lab_names)
     return pa.table(cols)
+
+
+def _sorted_codes(col):
+    """String column -> (names sorted as np.unique sorts them, int64 code of every row in that order), through
+    arrow's dictionary encoding instead of a string sort over all rows."""
+    d = (col.combine_chunks() if isinstance(col, pa.ChunkedArray) else col).dictionary_encode()
+    names = np.asarray(d.dictionary.to_pylist(), dtype=object).astype(str)
+    order = np.argsort(names, kind="stable")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    return names[order], rank[d.indices.to_numpy(zero_copy_only=False).astype(np.int64)]
+
+
+def _string_column(codes, names) -> pa.Array:
+    """names[codes] as a plain string column (built as a dictionary array, then decoded by arrow)."""
+    return pa.DictionaryArray.from_arrays(pa.array(np.asarray(codes, dtype=np.int32)),
+                                          pa.array([str(x) for x in names], pa.string())).cast(pa.string())
+
+
+def segments_table_from_blocks(blocks, labels) -> pa.Table:
+    """Per-file column blocks (uid, onset, offset, duration, label_codes) -> the segment table of segments_table()."""
+    if not blocks:
+        return segments_table([])
+    lens = np.array([len(b[1]) for b in blocks], dtype=np.int64)
+    cat = lambda k, dt: np.concatenate([np.asarray(b[k], dtype=dt) for b in blocks]) if lens.sum() else np.empty(0, dt)
+    return pa.table({"uid": _string_column(np.repeat(np.arange(len(blocks)), lens), [b[0] for b in blocks]),
+                     "onset": pa.array(cat(1, np.float64)), "offset": pa.array(cat(2, np.float64)),
+                     "duration": pa.array(cat(3, np.float64)), "label": _string_column(cat(4, np.int32), labels)},
+                    schema=SEGMENT_SCHEMA)
 
 
 # --------------------------------------------------------------------------- outputs / resume
