@@ -126,6 +126,20 @@ int vtc_decode_files(vtc_model* m, const float* logits /*[dev]*/, const int64_t*
                      int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit /*[host]*/,
                      double* mean_sigmoid /*[host]*/, void* stream);
 
+/* Two-step form of vtc_decode / vtc_decode_files for callers that keep the GPU fed (the pipeline's GPU thread; the
+ * reference runs forward, .cpu() and the Python decode strictly one after the other, vtc.py:236-268).  _launch enqueues
+ * the decode kernels and the copies of their results into pinned memory on `stream` and returns without waiting; the
+ * caller may then enqueue more work on that stream (the next forward); _collect waits only for what was enqueued up to
+ * _launch and hands out the runs exactly as vtc_decode_files does (n_files = 1, file_rows = {0, n_frames}: as
+ * vtc_decode, out_file all 0).  max_logit / mean_sigmoid ([n_files], may be null) are filled if want_summary was set.
+ * One decode may be in flight per model.  On VTC_ERR_CAPACITY the results stay parked and *n_out tells the room needed. */
+int vtc_decode_launch(vtc_model* m, const float* logits /*[dev]*/, const int64_t* file_rows /*[host] n_files+1*/,
+                      int32_t n_files, const float* lo_logit /*[host]*/, const float* hi_logit /*[host]*/,
+                      int32_t want_summary, void* stream);
+int vtc_decode_collect(vtc_model* m, int32_t* out_file /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,
+                       int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit /*[host]*/,
+                       double* mean_sigmoid /*[host]*/);
+
 /* Audio front-end of apply_model_on_audio (src/pipeline/vtc.py:236-243 decodes the file to mono 16 kHz float inside
  * segma before the model runs): interleaved PCM already in device memory -> mono float32 at 16 kHz, on `stream`.
  *   format 0 = int16 (scaled by 1/32768), 1 = float32; channels are averaged; sr_in != 16000 is resampled with the

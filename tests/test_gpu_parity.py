@@ -609,6 +609,28 @@ def test_multi_recording_batch_equals_per_recording(weights):
         assert list(s[sel]) == list(ss) and list(e[sel]) == list(se) and list(lab[sel]) == list(sl), i
         ref = O.apply_model_on_waveform(weights, w.cpu().numpy(), 4.0)
         assert (mine.cpu() - ref).abs().max().item() <= LOGIT_TOL
+    # two-step form (vtc_decode_launch / vtc_decode_collect): same runs and summaries, also with a forward enqueued between
+    # the two steps; one decode in flight at a time
+    want = eng.decode_files(logits.contiguous(), rows, lo, hi, summary=True)
+    eng.decode_launch(logits.contiguous(), rows, lo, hi, summary=True)
+    with pytest.raises(RuntimeError, match="not been collected"):
+        eng.decode_launch(logits.contiguous(), rows, lo, hi)
+    other = eng.infer_waveform(wavs[7], batch_size=8)                 # queued behind the decode, runs while we collect
+    got = eng.decode_collect()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(RuntimeError, match="without vtc_decode_launch"):
+        eng._pending_decode = (1, False, None)
+        eng.decode_collect()
+    single = eng.infer_waveform(wavs[5], batch_size=8).contiguous()
+    ss, se, sl, smax, smean = eng.decode(single, lo, hi)
+    eng.decode_launch(single, [0, single.shape[0]], lo, hi, summary=True)
+    f1, s1, e1, l1, mx1, mean1 = eng.decode_collect()
+    assert not f1.any() and list(s1) == list(ss) and list(e1) == list(se) and list(l1) == list(sl)
+    assert float(mx1[0]) == smax and float(mean1[0]) == smean
+    eng.decode_launch(logits.contiguous(), [0, 0, 0], lo, hi, summary=True)   # recordings without rows
+    f0, s0, e0, l0, mx0, mean0 = eng.decode_collect()
+    assert len(f0) == 0 and list(mean0) == [0.0, 0.0] and np.isneginf(mx0).all()
+    assert torch.equal(other, eng.infer_waveform(wavs[7], batch_size=8))
     # a boundary inside an active run splits it: all-active logits, two recordings of 5 and 7 frames
     hot = torch.full((12, 4), 5.0, device="cuda")
     f2, s2, e2, l2 = eng.decode_files(hot, np.array([0, 5, 12]), lo, hi)

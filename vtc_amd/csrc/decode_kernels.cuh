@@ -171,4 +171,13 @@ __global__ __launch_bounds__(256) void file_summary_kernel(const float* __restri
   }
 }
 
+// First frame of every recording of a multi-recording row layout (rows[f] = first row of recording f).
+__global__ void mark_file_starts_kernel(const long long* __restrict__ rows, int n_files, long long n, unsigned char* __restrict__ mask) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n_files) {
+    const long long r = rows[f];
+    if (r < n) mask[r] = 1;
+  }
+}
+
 }  // namespace vtc

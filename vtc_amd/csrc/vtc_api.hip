@@ -87,6 +87,13 @@ struct vtc_model {
   int fsum_cap = 0;
   double *dec_sig = nullptr, *dec_summary = nullptr;
   float* dec_max = nullptr;
+  // vtc_decode_launch / vtc_decode_collect: one decode in flight, results parked in pinned host memory
+  char* dec_host = nullptr;
+  size_t dec_host_cap = 0;
+  hipEvent_t dec_event = nullptr;
+  bool dec_active = false, dec_want_summary = false;
+  long long dec_n = 0, dec_rcap = 0;
+  std::vector<int64_t> dec_rows;
 
   int debug_stop = -1;
   bool big_tiles = true;   // 256x256 8-phase GEMM (VTC_GEMM_TILE=128 selects the 128x128 kernel, for A/B runs)
@@ -403,6 +410,8 @@ void vtc_destroy(vtc_model* m) {
   for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
                   (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart, (void*)m->fsum_rows, (void*)m->fsum_out})
     if (p) (void)hipFree(p);
+  if (m->dec_host) (void)hipHostFree(m->dec_host);
+  if (m->dec_event) (void)hipEventDestroy(m->dec_event);
   if (m->h_stage) (void)hipHostFree(m->h_stage);
   for (auto& e : m->slot_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -760,6 +769,182 @@ int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows
       out_end[at] = ((int64_t)re[l][k] - file_rows[f]) * kRfStep + kRfSize;
       out_label[at] = l;
     }
+  return VTC_OK;
+}
+
+// ---- two-step decode: everything the GPU has to do is enqueued by _launch (kernels and the copies of their results
+// into pinned memory), so the caller can queue the next forward right behind it and _collect waits for nothing newer.
+namespace {
+constexpr size_t kDecHostHead = 256;   // totals (2 * VTC_MAX_LABELS ints) at 0, summary (2 doubles) at 128
+
+int ensure_file_scratch(vtc_model* m, int n_files) {
+  if (n_files <= m->fsum_cap) return 0;
+  if (m->fsum_rows) (void)hipFree(m->fsum_rows);
+  if (m->fsum_out) (void)hipFree(m->fsum_out);
+  m->fsum_rows = nullptr; m->fsum_out = nullptr; m->fsum_cap = 0;
+  const int capf = n_files + n_files / 2 + 64;
+  HIP_TRY(m, hipMalloc((void**)&m->fsum_rows, sizeof(long long) * (capf + 1)));
+  HIP_TRY(m, hipMalloc((void**)&m->fsum_out, sizeof(double) * 2 * capf));
+  m->fsum_cap = capf;
+  return 0;
+}
+}  // namespace
+
+int vtc_decode_launch(vtc_model* m, const float* logits, const int64_t* file_rows, int32_t n_files, const float* lo,
+                      const float* hi, int32_t want_summary, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !file_rows || !lo || !hi) return fail(m, VTC_ERR_ARG, "null argument");
+  if (m->dec_active) return fail(m, VTC_ERR_ARG, "vtc_decode_launch: the previous launch has not been collected");
+  if (n_files < 1) return fail(m, VTC_ERR_ARG, "n_files %d < 1", n_files);
+  if (file_rows[0] != 0) return fail(m, VTC_ERR_ARG, "file_rows[0] must be 0");
+  for (int f = 0; f < n_files; ++f)
+    if (file_rows[f + 1] < file_rows[f]) return fail(m, VTC_ERR_ARG, "file_rows must not decrease (file %d)", f);
+  const int64_t n = file_rows[n_files];
+  if (n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int nl = m->spec.n_labels;
+  m->dec_rows.assign(file_rows, file_rows + n_files + 1);
+  m->dec_n = n;
+  m->dec_want_summary = want_summary != 0;
+  if (!m->dec_event) HIP_TRY(m, hipEventCreateWithFlags(&m->dec_event, hipEventDisableTiming));
+  if (n == 0) {   // nothing to decode: collect returns zero runs
+    m->dec_rcap = 0;
+    HIP_TRY(m, hipEventRecord(m->dec_event, s));
+    m->dec_active = true;
+    return VTC_OK;
+  }
+  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  if (int rc = ensure_file_scratch(m, n_files)) return rc;
+  const long long rcap = n / 2 + 1, dcap = m->dec_frames_cap / 2 + 1;
+  const size_t off_fsum = kDecHostHead, off_rows = off_fsum + sizeof(double) * 2 * (size_t)n_files;
+  const size_t off_rs = (off_rows + sizeof(int64_t) * ((size_t)n_files + 1) + 63) & ~(size_t)63;
+  const size_t off_re = off_rs + sizeof(int) * (size_t)nl * rcap, need = off_re + sizeof(int) * (size_t)nl * rcap;
+  if (need > m->dec_host_cap) {
+    if (m->dec_host) (void)hipHostFree(m->dec_host);
+    m->dec_host = nullptr; m->dec_host_cap = 0;
+    const size_t cap = need + need / 4 + 4096;
+    HIP_TRY(m, hipHostMalloc((void**)&m->dec_host, cap, hipHostMallocDefault));
+    m->dec_host_cap = cap;
+  }
+  m->dec_rcap = rcap;
+  char* h = m->dec_host;
+  const unsigned char* fstart = nullptr;
+  if (n_files > 1) {   // runs must not cross a recording: mark the first frame of every recording
+    memcpy(h + off_rows, file_rows, sizeof(int64_t) * ((size_t)n_files + 1));
+    HIP_TRY(m, hipMemcpyAsync(m->fsum_rows, h + off_rows, sizeof(int64_t) * ((size_t)n_files + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(m, hipMemsetAsync(m->dec_fstart, 0, (size_t)n + 1, s));
+    hipLaunchKernelGGL(mark_file_starts_kernel, dim3((n_files + 255) / 256), dim3(256), 0, s, m->fsum_rows, n_files, (long long)n,
+                       m->dec_fstart);
+    fstart = m->dec_fstart;
+    if (want_summary) {
+      LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4, s,
+             hipLaunchKernelGGL(file_summary_kernel, dim3(n_files), dim3(256), 0, s, logits, nl, m->fsum_rows, m->fsum_out));
+      HIP_TRY(m, hipMemcpyAsync(h + off_fsum, m->fsum_out, sizeof(double) * 2 * n_files, hipMemcpyDeviceToHost, s));
+    }
+  }
+  DecodeParams p{};
+  p.logits = logits; p.n = n; p.nl = nl; p.nblk = (int)((n + 255) / 256);
+  p.file_start = fstart;
+  for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
+  LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4 * 2, s, {
+    hipLaunchKernelGGL(decode_count_kernel, dim3(p.nblk), dim3(256), 0, s, p, m->dec_counts, m->dec_sig, m->dec_max);
+    hipLaunchKernelGGL(decode_scan_kernel, dim3(2 * nl), dim3(1024), 0, s, m->dec_counts, p.nblk, m->dec_totals, m->dec_sig,
+                       m->dec_max, m->dec_summary);
+    hipLaunchKernelGGL(decode_emit_kernel, dim3(p.nblk), dim3(256), 0, s, p, m->dec_counts, dcap, m->dec_start, m->dec_end);
+  });
+  HIP_TRY(m, hipMemcpyAsync(h, m->dec_totals, sizeof(int) * 2 * nl, hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipMemcpyAsync(h + 128, m->dec_summary, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  // the run lists at their full capacity (n/2 + 1 per label): their lengths are only known on the device, and a
+  // second, length-sized copy would have to queue behind whatever the caller enqueues next
+  HIP_TRY(m, hipMemcpy2DAsync(h + off_rs, sizeof(int) * rcap, m->dec_start, sizeof(int) * dcap, sizeof(int) * rcap, nl,
+                              hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipMemcpy2DAsync(h + off_re, sizeof(int) * rcap, m->dec_end, sizeof(int) * dcap, sizeof(int) * rcap, nl,
+                              hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipEventRecord(m->dec_event, s));
+  HIP_TRY(m, hipGetLastError());
+  m->dec_active = true;
+  return VTC_OK;
+}
+
+int vtc_decode_collect(vtc_model* m, int32_t* out_file, int64_t* out_start, int64_t* out_end, int32_t* out_label, int64_t cap,
+                       int64_t* n_out, float* max_logit, double* mean_sigmoid) {
+  if (!m) return VTC_ERR_ARG;
+  if (!n_out || (cap > 0 && (!out_file || !out_start || !out_end || !out_label))) return fail(m, VTC_ERR_ARG, "null argument");
+  if (!m->dec_active) return fail(m, VTC_ERR_ARG, "vtc_decode_collect without vtc_decode_launch");
+  HIP_TRY(m, hipSetDevice(m->device));
+  HIP_TRY(m, hipEventSynchronize(m->dec_event));
+  const int nl = m->spec.n_labels, n_files = (int)m->dec_rows.size() - 1;
+  const int64_t* rows = m->dec_rows.data();
+  const long long n = m->dec_n, rcap = m->dec_rcap;
+  *n_out = 0;
+  if (n == 0) {
+    for (int f = 0; f < n_files; ++f) {
+      if (max_logit) max_logit[f] = -INFINITY;
+      if (mean_sigmoid) mean_sigmoid[f] = 0.0;
+    }
+    m->dec_active = false;
+    return VTC_OK;
+  }
+  const char* h = m->dec_host;
+  const int* totals = (const int*)h;
+  const double* summary = (const double*)(h + 128);
+  const size_t off_fsum = kDecHostHead, off_rows = off_fsum + sizeof(double) * 2 * (size_t)n_files;
+  const size_t off_rs = (off_rows + sizeof(int64_t) * ((size_t)n_files + 1) + 63) & ~(size_t)63;
+  const int* rs = (const int*)(h + off_rs);
+  const int* re = rs + (size_t)nl * rcap;
+  long long total = 0;
+  for (int l = 0; l < nl; ++l) {
+    if (totals[l] != totals[nl + l] || totals[l] < 0 || totals[l] > rcap) {
+      m->dec_active = false;
+      return fail(m, VTC_ERR_HIP, "decode: label %d has %d starts and %d ends (capacity %lld)", l, totals[l], totals[nl + l], rcap);
+    }
+    total += totals[l];
+  }
+  *n_out = total;
+  if (total > cap)   // the results stay parked: call again with room for *n_out runs
+    return fail(m, VTC_ERR_CAPACITY, "decode: %lld intervals, caller capacity %lld", total, (long long)cap);
+  if (m->dec_want_summary) {
+    if (n_files == 1) {
+      if (max_logit) max_logit[0] = (float)summary[1];
+      if (mean_sigmoid) mean_sigmoid[0] = summary[0] / ((double)n * nl);
+    } else {
+      const double* hsum = (const double*)(h + off_fsum);
+      for (int f = 0; f < n_files; ++f) {
+        const long long cnt = (rows[f + 1] - rows[f]) * nl;
+        if (max_logit) max_logit[f] = cnt ? (float)hsum[2 * f + 1] : -INFINITY;
+        if (mean_sigmoid) mean_sigmoid[f] = cnt ? hsum[2 * f] / (double)cnt : 0.0;
+      }
+    }
+  }
+  // recording of each run, then a stable counting sort by recording (as vtc_decode_files)
+  std::vector<long long> per_file((size_t)n_files + 1, 0);
+  std::vector<int> run_file((size_t)total);
+  long long at0 = 0;
+  for (int l = 0; l < nl; ++l) {
+    int f = 0;
+    for (int k = 0; k < totals[l]; ++k) {
+      const int r = rs[(size_t)l * rcap + k];
+      while (f + 1 < n_files && r >= rows[f + 1]) ++f;
+      run_file[(size_t)at0 + k] = f;
+      per_file[(size_t)f + 1]++;
+    }
+    at0 += totals[l];
+  }
+  for (int f = 0; f < n_files; ++f) per_file[(size_t)f + 1] += per_file[(size_t)f];
+  at0 = 0;
+  for (int l = 0; l < nl; ++l) {
+    for (int k = 0; k < totals[l]; ++k) {
+      const int f = run_file[(size_t)at0 + k];
+      const long long at = per_file[(size_t)f]++;
+      out_file[at] = f;
+      out_start[at] = ((int64_t)rs[(size_t)l * rcap + k] - rows[f]) * kRfStep;
+      out_end[at] = ((int64_t)re[(size_t)l * rcap + k] - rows[f]) * kRfStep + kRfSize;
+      out_label[at] = l;
+    }
+    at0 += totals[l];
+  }
+  m->dec_active = false;
   return VTC_OK;
 }
 

@@ -204,6 +204,44 @@ class VtcEngine:
         out = (fidx[:k].copy(), s[:k].copy(), e[:k].copy(), lab[:k].copy())
         return out + (mx, mean) if summary else out
 
+    def decode_launch(self, logits: torch.Tensor, file_rows, lo_logit, hi_logit, summary: bool = False) -> None:
+        """First half of decode_files (include/vtc_amd.h: vtc_decode_launch): enqueue the decode of these rows on the
+        current stream and return at once; more work (the next forward) may be enqueued before decode_collect().
+        file_rows = [0, n_frames] decodes one recording.  `logits` must stay alive until decode_collect()."""
+        if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
+        file_rows = np.ascontiguousarray(file_rows, dtype=np.int64)
+        if int(file_rows[-1]) > int(logits.shape[0]):
+            raise ValueError("file_rows reach past the logits buffer")
+        lo = np.ascontiguousarray(lo_logit, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_logit, dtype=np.float32)
+        if len(lo) != self.n_labels or len(hi) != self.n_labels:
+            raise ValueError("need one lower and one upper bound per label")
+        self._pending_decode = (len(file_rows) - 1, bool(summary), logits)
+        L.check(self._lib.vtc_decode_launch(self._handle, C.c_void_p(logits.data_ptr()), file_rows.ctypes.data_as(L._i64p),
+                                            len(file_rows) - 1, lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
+                                            int(summary), self._stream()), self._handle)
+
+    def decode_collect(self):
+        """Second half: wait for the launched decode (not for anything enqueued after it) and return what decode_files
+        returns: (file_index, start_samples, end_samples, label_index[, max_logit, mean_sigmoid])."""
+        nf, summary, _keep = self._pending_decode
+        mx = np.empty(nf, dtype=np.float32) if summary else None
+        mean = np.empty(nf, dtype=np.float64) if summary else None
+        n_out = C.c_int64(0)
+        args_tail = (mx.ctypes.data_as(L._f32p) if summary else None, mean.ctypes.data_as(L._f64p) if summary else None)
+        rc = self._lib.vtc_decode_collect(self._handle, None, None, None, None, 0, C.byref(n_out), *args_tail)
+        k = n_out.value
+        fidx, s = np.empty(k, dtype=np.int32), np.empty(k, dtype=np.int64)
+        e, lab = np.empty(k, dtype=np.int64), np.empty(k, dtype=np.int32)
+        if rc == L.ERR_CAPACITY:          # the size is known now: second call copies the runs out
+            rc = self._lib.vtc_decode_collect(self._handle, fidx.ctypes.data_as(L._i32p), s.ctypes.data_as(L._i64p),
+                                              e.ctypes.data_as(L._i64p), lab.ctypes.data_as(L._i32p), k, C.byref(n_out), *args_tail)
+        self._pending_decode = None
+        L.check(rc, self._handle)
+        out = (fidx, s, e, lab)
+        return out + (mx, mean) if summary else out
+
     # ------------------------------------------------------------------ audio front-end
     def prepare_audio(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:
         """Interleaved PCM on the device, int16 or float32, shape (n,) or (n, channels) -> mono float32 at 16 kHz

@@ -68,6 +68,8 @@ SYMBOLS = {
     "vtc_infer_waveforms": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i64p, C.c_int32, C.c_int32, C.c_void_p, _i64p, C.c_void_p]),
     "vtc_decode_files": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, C.c_int32, _f32p, _f32p, _i32p, _i64p, _i64p, _i32p, C.c_int64,
                                    _i64p, _f32p, _f64p, C.c_void_p]),
+    "vtc_decode_launch": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
+    "vtc_decode_collect": (C.c_int, [C.c_void_p, _i32p, _i64p, _i64p, _i32p, C.c_int64, _i64p, _f32p, _f64p]),
     "vtc_resampled_length": (C.c_int64, [C.c_int64, C.c_int32]),
     "vtc_prepare_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                     _i64p, C.c_void_p]),

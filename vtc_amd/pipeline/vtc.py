@@ -123,20 +123,19 @@ def stage_audio(path, engine) -> torch.Tensor:
 def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logits: bool):
     """GPU-thread stage: forward + threshold/run-length decode; only the decoded triples (and, on request, the
     logits) come back to the host."""
-    return gpu_collect(engine, gpu_launch(engine, [gpu_wav], batch_size, grouped=False), lo, hi, want_logits)[0]
+    return gpu_group_stage(engine, [gpu_wav], lo, hi, batch_size, want_logits, grouped=False)[0]
 
 
-def gpu_group_stage(engine, wavs, lo, hi, batch_size: int, want_logits: bool):
+def gpu_group_stage(engine, wavs, lo, hi, batch_size: int, want_logits: bool, grouped: bool = True):
     """GPU-thread stage for several short recordings: their windows share forward passes (vtc_infer_waveforms) and one
-    segmented decode with per-recording sigmoid summaries (vtc_decode_files).  Returns one gpu_stage-shaped tuple per
-    recording.  A 30 s file is 8 windows of 4 s: alone it would use 1/16 of a 128-window batch."""
-    return gpu_collect(engine, gpu_launch(engine, wavs, batch_size, grouped=True), lo, hi, want_logits)
+    segmented decode with per-recording sigmoid summaries.  Returns one gpu_stage-shaped tuple per recording.
+    A 30 s file is 8 windows of 4 s: alone it would use 1/16 of a 128-window batch."""
+    forward = gpu_launch(engine, wavs, batch_size, grouped)
+    return gpu_collect(engine, gpu_decode_launch(engine, forward, lo, hi, want_logits), want_logits)
 
 
 def gpu_launch(engine, wavs, batch_size: int, grouped: bool):
-    """First half of the GPU stage: enqueue the forward passes on the current stream and return without waiting.
-    The decode (which ends in a host synchronisation) is the second half, gpu_collect, so that the GPU thread can
-    enqueue the NEXT forward before it blocks on this one: the GPU never waits for Python between recordings."""
+    """GPU stage, step 1: enqueue the forward passes on the current stream; nothing waits."""
     cur = torch.cuda.current_stream(engine.device)
     for w in wavs:
         w.record_stream(cur)
@@ -144,34 +143,42 @@ def gpu_launch(engine, wavs, batch_size: int, grouped: bool):
         if grouped:
             logits, rows = engine.infer_waveforms(wavs, batch_size)
         else:
-            logits, rows = engine.infer_waveform(wavs[0], batch_size), None
-    done = torch.cuda.Event()
-    done.record(cur)
-    return logits, rows, done, [int(w.numel()) for w in wavs]
+            logits = engine.infer_waveform(wavs[0], batch_size)
+            rows = np.array([0, int(logits.shape[0])], dtype=np.int64)
+    return logits, rows, [int(w.numel()) for w in wavs]
 
 
-def gpu_collect(engine, launched, lo, hi, want_logits: bool):
-    """Second half: threshold + run-length decode on a side stream that waits for the forward's event (a forward
-    enqueued in between keeps running underneath), then the small D2H copies.  One gpu_stage-shaped tuple per recording."""
-    logits, rows, done, n_samples = launched
-    side = getattr(_TLS, "decode_stream", None)
-    if side is None:
-        side = _TLS.decode_stream = torch.cuda.Stream(engine.device)
-    side.wait_event(done)
-    logits.record_stream(side)
-    with torch.no_grad(), torch.cuda.stream(side):
-        if rows is None:
-            starts, ends, lab, max_logit, mean_sig = engine.decode(logits, lo, hi)
-            cpu_logits = logits.cpu() if want_logits else None
-            return [(starts, ends, lab, max_logit, mean_sig, n_samples[0], cpu_logits)]
-        fidx, starts, ends, lab, mx, mean = engine.decode_files(logits, rows, lo, hi, summary=True)
-        bounds = np.searchsorted(fidx, np.arange(len(n_samples) + 1))      # fidx is sorted (recording-major output)
-        out = []
-        for f, n in enumerate(n_samples):
-            a, b = int(bounds[f]), int(bounds[f + 1])
-            cpu_logits = logits[int(rows[f]):int(rows[f + 1])].cpu() if want_logits else None
-            out.append((starts[a:b], ends[a:b], lab[a:b], float(mx[f]), float(mean[f]), n, cpu_logits))
-        return out
+def gpu_decode_launch(engine, forward, lo, hi, want_logits: bool):
+    """Step 2: enqueue, behind the forward and still without waiting, the threshold / run-length decode
+    (vtc_decode_launch: kernels + copies of the results into pinned memory) and, on request, the copy of the logits.
+    One decode can be in flight per engine, so the GPU thread's order is: forward(i+1), collect(i), decode_launch(i+1);
+    the next forward is then enqueued behind this decode, and the GPU never waits for Python between batches."""
+    logits, rows, n_samples = forward
+    with torch.no_grad():
+        engine.decode_launch(logits, rows, lo, hi, summary=True)
+        cpu_logits, copied = None, None
+        if want_logits:
+            cpu_logits = torch.empty(logits.shape, dtype=logits.dtype, pin_memory=True)
+            cpu_logits.copy_(logits, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(torch.cuda.current_stream(engine.device))
+    return logits, rows, cpu_logits, copied, n_samples
+
+
+def gpu_collect(engine, launched, want_logits: bool):
+    """Step 3: wait for the decode enqueued by gpu_decode_launch (a forward enqueued after it keeps running) and split
+    the runs by recording.  One gpu_stage-shaped tuple per recording."""
+    logits, rows, cpu_logits, copied, n_samples = launched
+    fidx, starts, ends, lab, mx, mean = engine.decode_collect()
+    if copied is not None:
+        copied.synchronize()
+    bounds = np.searchsorted(fidx, np.arange(len(n_samples) + 1))      # fidx is sorted (recording-major output)
+    out = []
+    for f, n in enumerate(n_samples):
+        a, b = int(bounds[f]), int(bounds[f + 1])
+        part = cpu_logits[int(rows[f]):int(rows[f + 1])].clone() if want_logits else None
+        out.append((starts[a:b], ends[a:b], lab[a:b], float(mx[f]), float(mean[f]), n, part))
+    return out
 
 
 def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
@@ -367,14 +374,14 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         serial_gpu = os.environ.get("VTC_SERIAL_GPU_STAGE") == "1"    # diagnostic: collect right after launching (A/B timing)
 
         def drain():
-            """Collect the batch whose forward is in flight (decode + host sync) and publish its results."""
+            """Collect the batch whose forward + decode are in flight (host sync) and publish its results."""
             nonlocal pending
             if pending is None:
                 return
             (items, launched), pending = pending, None
             t_col = time.perf_counter()
             try:
-                outs = gpu_collect(engine, launched, lo, hi, save_logits)
+                outs = gpu_collect(engine, launched, save_logits)
                 for (i, _), o in zip(items, outs):
                     results[i].set_result(o)
             except Exception as e:
@@ -392,22 +399,26 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     results[i].set_exception(e1)
 
         def run_group():
-            """Enqueue the forward of the current group, THEN collect the previous one: its decode and host
-            synchronisation overlap the forward that was just enqueued."""
+            """Enqueue the forward of the current group, collect the previous group (its forward and decode were
+            enqueued one call ago), then enqueue this group's decode behind its forward."""
             nonlocal group, group_windows, pending
             if not group:
                 return
             items, group, group_windows = group, [], 0
             t_run = time.perf_counter()
             try:
-                launched = gpu_launch(engine, [w for _, w in items], batch_size, grouped=len(items) > 1)
+                forward = gpu_launch(engine, [w for _, w in items], batch_size, len(items) > 1)
             except Exception as e:
                 drain()
                 redo(items, e)
                 return
             _tick("gpu_launch", t_run)
             drain()
-            pending = (items, launched)
+            try:
+                pending = (items, gpu_decode_launch(engine, forward, lo, hi, save_logits))
+            except Exception as e:
+                redo(items, e)
+                return
             if serial_gpu:
                 drain()
             _tick("gpu_run", t_run)
