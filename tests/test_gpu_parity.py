@@ -702,7 +702,7 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
     assert merged.schema.names == raw.schema.names and merged.num_rows <= raw.num_rows
     # resume: nothing with segments is recomputed
     calls = []
-    monkeypatch.setattr(clips, "run_group", lambda eng, group, *a, _f=clips.run_group: (calls.append([c for c, _ in group]), _f(eng, group, *a))[1])
+    monkeypatch.setattr(clips, "launch_group", lambda eng, group, *a, _f=clips.launch_group: (calls.append([c for c, _ in group]), _f(eng, group, *a))[1])
     clips.main("ds", **common)
     done = {r["clip_id"] for r in rows}
     assert all(c not in done for g in calls for c in g)

@@ -23,8 +23,10 @@ from __future__ import annotations
 import argparse
 import io
 import logging
+import queue
 import sys
 import tarfile
+import threading
 import time
 from pathlib import Path
 
@@ -35,14 +37,15 @@ import pyarrow.parquet as pq
 import torch
 
 from ..audio import decode_flac, to_float32
-from ..core.intervals import intervals_to_segments
+from ..core.intervals import intervals_to_columns
 from ..engine import RF_SIZE
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
 from ..segma_compat.models import Models
 from ..segma_compat.utils.encoders import MultiLabelEncoder
-from ..utils import atomic_write_parquet, get_dataset_paths, hhmmss, merge_segments, set_seeds, shard_list
+from ..utils import (atomic_write_parquet, get_dataset_paths, hhmmss, merge_segments, segments_table_from_blocks, set_seeds,
+                     shard_list)
 
 logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
 logger = logging.getLogger("vtc_clips")
@@ -90,25 +93,37 @@ def decode_clip(sample):
     raise ValueError("no audio found in sample")
 
 
-def clips_table(rows: list[dict]) -> pa.Table:
-    return pa.table({"clip_id": [r["uid"] for r in rows], "onset": [r["onset"] for r in rows],
-                     "offset": [r["offset"] for r in rows], "duration": [r["duration"] for r in rows],
-                     "label": [r["label"] for r in rows]}, schema=CLIP_SCHEMA)
+def clips_table(blocks, labels) -> pa.Table:
+    """Per-clip column blocks (clip_id, onset, offset, duration, label codes) -> the clip segment table."""
+    return segments_table_from_blocks(blocks, labels).rename_columns(CLIP_SCHEMA.names).cast(CLIP_SCHEMA)
+
+
+def launch_group(engine, group, batch_size):
+    """group: list of (clip_id, device waveform).  Enqueue one batched forward over all clips; nothing waits."""
+    with torch.no_grad():
+        logits, file_rows = engine.infer_waveforms([w for _, w in group], batch_size)
+    return logits, file_rows
+
+
+def collect_group(engine, group):
+    """Wait for the decode launched for `group` and turn its runs into one column block per clip (same values as
+    core.intervals.intervals_to_segments on every clip)."""
+    fidx, starts, ends, lab = engine.decode_collect()
+    onset, offset, duration, keep = intervals_to_columns(starts, ends)
+    bounds = np.searchsorted(fidx, np.arange(len(group) + 1))          # fidx is sorted (recording-major output)
+    blocks = []
+    for f, (clip_id, _) in enumerate(group):
+        a, b = int(bounds[f]), int(bounds[f + 1])
+        k = keep[a:b]
+        blocks.append((clip_id, onset[a:b][k], offset[a:b][k], duration[a:b][k], lab[a:b][k]))
+    return blocks
 
 
 def run_group(engine, group, lo, hi, labels, batch_size):
-    """group: list of (clip_id, device waveform).  One batched forward + one segmented decode -> segment rows."""
-    wavs = [w for _, w in group]
-    with torch.no_grad():
-        logits, file_rows = engine.infer_waveforms(wavs, batch_size)
-        fidx, starts, ends, lab = engine.decode_files(logits, file_rows, lo, hi)
-    per_clip = [[] for _ in group]
-    for f, s, e, k in zip(fidx, starts, ends, lab):
-        per_clip[int(f)].append((int(s), int(e), labels[int(k)]))
-    rows = []
-    for (clip_id, _), intervals in zip(group, per_clip):
-        rows.extend(intervals_to_segments(intervals, clip_id))
-    return rows
+    """One batched forward + one segmented decode, synchronously -> one block per clip."""
+    logits, file_rows = launch_group(engine, group, batch_size)
+    engine.decode_launch(logits, file_rows, lo, hi)
+    return collect_group(engine, group)
 
 
 def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
@@ -165,37 +180,97 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
     step = engine.step
 
-    seg_rows: list[dict] = []
+    seg_blocks: list = []
     n_processed = n_skipped = n_errors = 0
     t0 = last_log_t = time.time()
     group, group_windows = [], 0
+    pending = None            # (group, logits): forward and decode enqueued, not collected yet
+
+    def redo(items, e):
+        nonlocal n_processed, n_errors
+        logger.warning(f"batch of {len(items)} clips failed ({e}); retrying one by one")
+        for item in items:       # a failing batch is retried clip by clip so one bad clip cannot take the others down
+            try:
+                seg_blocks.extend(run_group(engine, [item], lo, hi, labels, batch_size))
+                n_processed += 1
+            except Exception as e1:
+                logger.warning(f"{item[0]}: {e1}")
+                n_errors += 1
+
+    def drain():
+        nonlocal pending, n_processed
+        if pending is None:
+            return
+        (items, _logits), pending = pending, None
+        try:
+            seg_blocks.extend(collect_group(engine, items))
+            n_processed += len(items)
+        except Exception as e:
+            redo(items, e)
 
     def flush():
-        nonlocal group, group_windows, n_processed, n_errors
+        """forward(i+1), collect(i), decode_launch(i+1): the GPU already runs the next batch while this thread turns
+        the previous one into rows (per_clip restores the reference's one clip at a time, fully synchronous)."""
+        nonlocal group, group_windows, pending
         if not group:
             return
+        items, group, group_windows = group, [], 0
         try:
-            seg_rows.extend(run_group(engine, group, lo, hi, labels, batch_size))
-            n_processed += len(group)
-        except Exception as e:   # a failing batch is retried clip by clip so one bad clip cannot take the others down
-            logger.warning(f"batch of {len(group)} clips failed ({e}); retrying one by one")
-            for item in group:
-                try:
-                    seg_rows.extend(run_group(engine, [item], lo, hi, labels, batch_size))
-                    n_processed += 1
-                except Exception as e1:
-                    logger.warning(f"{item[0]}: {e1}")
-                    n_errors += 1
-        group, group_windows = [], 0
+            logits, file_rows = launch_group(engine, items, batch_size)
+        except Exception as e:
+            drain()
+            redo(items, e)
+            return
+        drain()
+        try:
+            engine.decode_launch(logits, file_rows, lo, hi)
+            pending = (items, logits)
+        except Exception as e:
+            redo(items, e)
+        if per_clip:
+            drain()
 
-    for tar_path in tar_files:
-        for sample in iter_tar_samples(tar_path):
-            clip_id = sample["__key__"]
-            if clip_id in completed:
+    # Reader thread: tar members -> PCM in memory (FLAC through the library's decoder, outside the GIL), a bounded queue
+    # ahead of the GPU loop.  Order is the tar order, as in the reference.
+    todo: queue.Queue = queue.Queue(maxsize=4 * max(batch_size, 16))
+    stop = threading.Event()
+
+    def reader():
+        try:
+            for tar_path in tar_files:
+                for sample in iter_tar_samples(tar_path):
+                    if stop.is_set():
+                        return
+                    clip_id = sample["__key__"]
+                    if clip_id in completed:
+                        todo.put((clip_id, None, None, None))
+                        continue
+                    try:
+                        pcm, sr = decode_clip(sample)
+                        todo.put((clip_id, pcm, sr, None))
+                    except Exception as e:
+                        todo.put((clip_id, None, None, e))
+        except BaseException as e:          # a broken tar must not leave the consumer waiting
+            todo.put((None, None, None, e))
+        finally:
+            todo.put(None)
+
+    reader_thread = threading.Thread(target=reader, name="clip-reader", daemon=True)
+    reader_thread.start()
+    try:
+        while True:
+            item = todo.get()
+            if item is None:
+                break
+            clip_id, pcm, sr, err = item
+            if clip_id is None:
+                raise err
+            if err is None and pcm is None:
                 n_skipped += 1
                 continue
             try:
-                pcm, sr = decode_clip(sample)
+                if err is not None:
+                    raise err
                 wav = engine.prepare_audio(torch.from_numpy(pcm).to(engine.device), sr)
                 if wav.numel() < RF_SIZE:
                     raise ValueError(f"audio too short: {wav.numel()} samples < receptive field {RF_SIZE}")
@@ -212,12 +287,20 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 rate = n_processed / max(now - t0, 1e-9)
                 logger.info(f"  {n_processed} processed, {n_skipped} skipped, {n_errors} errors  ({rate:.1f} clips/s)")
                 last_log_t = now
-    flush()
+        flush()
+        drain()
+    finally:
+        stop.set()
+        while reader_thread.is_alive():     # unblock a reader waiting on the full queue
+            try:
+                todo.get(timeout=0.05)
+            except queue.Empty:
+                pass
 
-    new_seg = clips_table(seg_rows)
+    new_seg = clips_table(seg_blocks, labels)
     if raw_path.exists() and completed:
         prev = pq.read_table(raw_path).cast(CLIP_SCHEMA)
-        new_ids = pa.array(sorted({r["uid"] for r in seg_rows}), pa.string())
+        new_ids = pa.array(sorted({b[0] for b in seg_blocks if len(b[1])}), pa.string())
         kept = prev.filter(pc.invert(pc.is_in(prev.column("clip_id"), value_set=new_ids))) if len(new_ids) else prev
         parts = [t for t in (kept, new_seg) if t.num_rows]
         seg_df = pa.concat_tables(parts) if parts else new_seg
