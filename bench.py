@@ -133,10 +133,27 @@ def main() -> None:
     lo = np.zeros(4, dtype=np.float32)            # sigmoid threshold 0.5 <=> logit 0
     hi = np.full(4, np.inf, dtype=np.float32)
 
+    # A step = forward of one batch + threshold / run-length decode of its logits, in the order the CLI's GPU thread uses
+    # (vtc_amd/pipeline/vtc.py): forward(i), collect(i-1), decode_launch(i).  Every step's runs reach the host inside the
+    # timed region (the last collect comes before the closing synchronize); two logits buffers alternate because the
+    # decode of step i-1 is still reading its buffer while forward(i) writes.
+    logits2 = [logits, torch.empty_like(logits)]
+    rows = np.array([0, args.batch * T], dtype=np.int64)
+    in_flight = [False]
+
+    def collect() -> int:
+        if not in_flight[0]:
+            return 0
+        in_flight[0] = False
+        return len(eng.decode_collect()[1])
+
     def one_step(i: int) -> int:
-        eng.forward_windows(arenas[i % n_arena], start, valid, dst, keep, logits)
-        s, e, lab, _, _ = eng.decode(logits, lo, hi)
-        return len(s)
+        buf = logits2[i % 2]
+        eng.forward_windows(arenas[i % n_arena], start, valid, dst, keep, buf)
+        n = collect()
+        eng.decode_launch(buf, rows, lo, hi, summary=True)
+        in_flight[0] = True
+        return n
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -145,6 +162,7 @@ def main() -> None:
 
     for i in range(args.warmup):
         one_step(i)
+    collect()
     barrier()
     every = max(1, args.profile_every)
     sampled = 0
@@ -159,6 +177,7 @@ def main() -> None:
         nseg += one_step(i)
         if sample:
             eng.profile_enable(False)
+    nseg += collect()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read() if not args.no_profile else None
