@@ -147,7 +147,8 @@ int vtc_decode_collect(vtc_model* m, int32_t* out_file /*[host]*/, int64_t* out_
  *   library the reference pulls in through segma (requirements.txt:393-394).  The rule itself is unpinned.
  * *n_out = vtc_resampled_length(n_in, sr_in) = ceil(n_in * 16000 / sr_in); VTC_ERR_CAPACITY if out_cap is smaller.
  * The per-rate filter table is built and kept in the handle on first use.  Unlike the other entry points this one may
- * be called from several threads at once on one handle (the pipeline's reader threads do), each on its own stream. */
+ * be called from several threads at once on one handle (the pipeline's reader threads do), each on its own stream, as
+ * long as vtc_profile_enable is off (the launch records are not locked). */
 int64_t vtc_resampled_length(int64_t n_in, int32_t sr_in);
 int vtc_prepare_audio(vtc_model* m, const void* pcm /*[dev] n_in x n_channels, interleaved*/, int32_t format, int64_t n_in,
                       int32_t n_channels, int32_t sr_in, float* out /*[dev]*/, int64_t out_cap, int64_t* n_out, void* stream);

@@ -217,14 +217,16 @@ class VtcEngine:
         hi = np.ascontiguousarray(hi_logit, dtype=np.float32)
         if len(lo) != self.n_labels or len(hi) != self.n_labels:
             raise ValueError("need one lower and one upper bound per label")
-        self._pending_decode = (len(file_rows) - 1, bool(summary), logits)
         L.check(self._lib.vtc_decode_launch(self._handle, C.c_void_p(logits.data_ptr()), file_rows.ctypes.data_as(L._i64p),
                                             len(file_rows) - 1, lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
                                             int(summary), self._stream()), self._handle)
+        self._pending_decode = (len(file_rows) - 1, bool(summary), logits)
 
     def decode_collect(self):
         """Second half: wait for the launched decode (not for anything enqueued after it) and return what decode_files
         returns: (file_index, start_samples, end_samples, label_index[, max_logit, mean_sigmoid])."""
+        if getattr(self, "_pending_decode", None) is None:
+            raise RuntimeError("decode_collect() without decode_launch()")
         nf, summary, _keep = self._pending_decode
         mx = np.empty(nf, dtype=np.float32) if summary else None
         mean = np.empty(nf, dtype=np.float64) if summary else None
