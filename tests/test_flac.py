@@ -43,6 +43,18 @@ def test_rfc9639_example_stream():
     assert sr == g["sample_rate"] and got.dtype == np.int16 and np.array_equal(got, want)
 
 
+def test_rfc9639_second_example_frame():
+    g = json.loads((GOLDEN / "flac_rfc9639_example2_frame2.json").read_text())
+    packed = (g["sample_rate"] << 44) | ((g["channels"] - 1) << 41) | ((g["bits_per_sample"] - 1) << 36) | len(g["samples"])
+    si = (16).to_bytes(2, "big") * 2 + bytes(3) + (23).to_bytes(3, "big") + packed.to_bytes(8, "big") + bytes(16)
+    data = b"fLaC" + bytes([0x80, 0, 0, 0x22]) + si + bytes.fromhex(g["frame_hex"])
+    want = np.array(g["samples"], dtype=np.int64)
+    assert want[:, 1].tolist() == [-9072, -8958, -9410] and not (want[:, 1] & 1).any()      # one wasted bit
+    pcm, _ = F.decode(data)
+    got, sr = decode_flac(data)
+    assert np.array_equal(pcm, want) and np.array_equal(got, want) and sr == 44100
+
+
 @pytest.mark.parametrize("bps", [8, 12, 16, 20, 24])
 @pytest.mark.parametrize("nch", [1, 2])
 def test_lossless_round_trip_all_subframe_types(bps, nch):
@@ -176,3 +188,31 @@ def test_aiff_against_the_standard_library_writer(tmp_path):
     body = b"AIFC" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd
     got, sr = decode_aiff(b"FORM" + struct.pack(">I", len(body)) + body)
     assert sr == 48000 and np.array_equal(got, x)
+
+
+def test_decoder_is_thread_safe_and_errors_are_per_thread():
+    """vtc_flac_decode runs on the pipeline's reader threads at the same time (ctypes releases the GIL): many threads,
+    different streams, every result exact; a failing call leaves its message for its own thread only."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    streams = []
+    for k in range(8):
+        x = tone(20000 + 997 * k, 1 + k % 2, 16, seed=40 + k)
+        streams.append((x, F.encode(x, 16000, subframe=("auto", "lpc", "fixed2", "verbatim")[k % 4], blocksize=1152)))
+
+    def work(k):
+        x, enc = streams[k % 8]
+        for _ in range(6):
+            got, sr = decode_flac(enc, verify_md5=True)
+            assert sr == 16000 and np.array_equal(got, as_decoded(x, 16))
+        if k % 3 == 0:
+            try:
+                decode_flac(b"not a flac stream at all")
+            except L.VtcError as e:
+                assert "fLaC" in str(e)
+                return "failed as expected"
+        return "ok"
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        out = list(pool.map(work, range(24)))
+    assert out.count("failed as expected") == 8 and out.count("ok") == 16
