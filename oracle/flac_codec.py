@@ -11,7 +11,8 @@ installed here, so the oracle restates the published format: RFC 9639 ("Free Los
 
 Pinned by: (1) the decoder reproduces the one-frame example stream of RFC 9639 appendix D.1 (bytes and expected
 samples in tests/golden/flac_rfc9639_example1.json; the stream's own CRC-8, CRC-16 and MD5 all check, which also pins
-the transcription of the bytes); (2) lossless round trips encode -> decode == input with the MD5 in STREAMINFO
+the transcription of the bytes) and the second frame of the appendix D.2 stream (flac_rfc9639_example2_frame2.json,
+self-checking through its CRCs); both are verbatim subframes with wasted bits; (2) lossless round trips encode -> decode == input with the MD5 in STREAMINFO
 (RFC 8.2) compared against hashlib's MD5 of the input.  Streams written by libFLAC itself are not available offline:
 beyond (1) the decoder is "parity unpinned" against real-encoder output.
 """
