@@ -774,6 +774,47 @@ def test_grid_cut_clips_reproduce_full_file_rows_and_align(weights, tmp_path, mo
     assert sum(int(r["n_matched"]) for r in m.values()) > 0
 
 
+def test_launcher_two_workers_shard_files_and_match_one_process(tmp_path, monkeypatch):
+    """one worker process per GPU, contiguous equal-count file shards, no collective.  Rehearsed with two
+    workers on the one GPU of the test box (--devices 0,0): shard_0 / shard_1 hold disjoint halves of the manifest and
+    together equal the single-process run; a rerun resumes from the union of both shards (nothing recomputed)."""
+    import os, subprocess, sys
+    from pathlib import Path
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    names = []
+    for k in range(7):
+        x = synth.synth_audio(5.0 + 2.3 * k, seed=700 + k)
+        from vtc_amd.audio import write_wav
+        write_wav(tmp_path / "audio" / f"r{k}.wav", x)
+        names.append(str(tmp_path / "audio" / f"r{k}.wav"))
+    for ds in ("two", "one"):
+        (tmp_path / "manifests" / f"{ds}.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    args = ["--config", str(tmp_path / "cfg.yml"), "--checkpoint", "synthetic:0", "--batch_size", "8"]
+    env = dict(os.environ, PYTHONPATH=str(Path(__file__).resolve().parents[1]))
+    cmd = [sys.executable, "-m", "vtc_amd.launcher", "two", "--gpus", "2", "--devices", "0,0", "--"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    cli.main("one", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8)
+    out2, out1 = tmp_path / "output" / "two", tmp_path / "output" / "one"
+    m0 = pq.read_table(out2 / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()
+    m1 = pq.read_table(out2 / "vtc_meta" / "shard_1.parquet").column("uid").to_pylist()
+    assert m0 == ["r0", "r1", "r2", "r3"] and m1 == ["r4", "r5", "r6"]          # shard_list: sizes 4, 3, contiguous
+    key = lambda r: (r["uid"], r["label"], r["onset"])
+    for kind in ("vtc_raw", "vtc_merged", "vtc_meta"):
+        both = sorted(pq.read_table(out2 / kind / "shard_0.parquet").to_pylist() +
+                      pq.read_table(out2 / kind / "shard_1.parquet").to_pylist(), key=lambda r: key(r) if "label" in r else r["uid"])
+        single = sorted(pq.read_table(out1 / kind / "shard_0.parquet").to_pylist(), key=lambda r: key(r) if "label" in r else r["uid"])
+        assert both == single, kind
+    before = {p: p.stat().st_mtime_ns for p in (out2 / "vtc_meta").glob("*.parquet")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "0 remaining" in (r.stdout + r.stderr)
+    assert sorted(pq.read_table(out2 / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()) == ["r0", "r1", "r2", "r3"]
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)

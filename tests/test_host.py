@@ -436,3 +436,28 @@ def test_columnar_segments_and_meta_equal_the_scalar_forms():
     assert got.equals(utils.segments_table(rows_all)) and got.schema == utils.SEGMENT_SCHEMA
     assert utils.segments_table_from_blocks([], labels).num_rows == 0
     assert utils.segments_table_from_blocks(blocks[:1], labels).num_rows == 0
+
+
+def test_launcher_builds_one_worker_per_device(monkeypatch):
+    """vtc_amd.launcher: options before "--" are the launcher's, everything after goes to every worker; worker i sees one
+    device and gets --array_id i --array_count N (the reference's SLURM array, slurm/vtc.slurm:10)."""
+    from vtc_amd import launcher
+    calls = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            calls.append((cmd, env["HIP_VISIBLE_DEVICES"], env["HSA_ENABLE_IPC_MODE_LEGACY"]))
+
+        def wait(self):
+            return 0 if len(calls) != 99 else 1
+
+    monkeypatch.setattr(launcher.subprocess, "Popen", lambda cmd, env: FakeProc(cmd, env))
+    assert launcher.main(["chunks30", "--gpus", "3", "--", "--checkpoint", "best.ckpt", "--balance"]) == 0
+    assert [c[1] for c in calls] == ["0", "1", "2"] and all(c[2] == "0" for c in calls)
+    for i, (cmd, _, _) in enumerate(calls):
+        assert cmd[1:] == ["-m", "vtc_amd.pipeline.vtc", "chunks30", "--array_id", str(i), "--array_count", "3",
+                           "--checkpoint", "best.ckpt", "--balance"]
+    calls.clear()
+    assert launcher.main(["ds", "--devices", "0,0", "--", "--batch_size", "8"]) == 0          # two workers on one GPU
+    assert [c[1] for c in calls] == ["0", "0"] and calls[1][0][-4:] == ["--array_count", "2", "--batch_size", "8"]
+    assert launcher.main(["ds", "--gpus", "3", "--devices", "0,1"]) == 2                       # count mismatch

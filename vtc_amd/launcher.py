@@ -21,20 +21,31 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("dataset")
     ap.add_argument("--gpus", type=int, default=0, help="workers to start (0 = every visible GPU)")
-    ap.add_argument("rest", nargs=argparse.REMAINDER, help="arguments after -- go to every worker")
+    ap.add_argument("--devices", default="", help="comma-separated device ids, one per worker (default 0..gpus-1); "
+                                                  "repeating an id puts several workers on one GPU (rehearsals on a small box)")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    rest = []
+    if "--" in argv:                     # everything after the first "--" goes to every worker, untouched
+        cut = argv.index("--")
+        argv, rest = argv[:cut], argv[cut + 1:]
     args = ap.parse_args(argv)
-    n = args.gpus
+    devices = [d.strip() for d in args.devices.split(",") if d.strip()]
+    n = args.gpus or len(devices)
     if n <= 0:
         import torch
         n = torch.cuda.device_count()   # counting devices does not initialise the GPU
     if n < 1:
         print("no GPU visible", file=sys.stderr)
         return 2
-    rest = [a for a in args.rest if a != "--"]
+    if devices and len(devices) != n:
+        print(f"--devices names {len(devices)} devices for {n} workers", file=sys.stderr)
+        return 2
+    if not devices:
+        devices = [str(i) for i in range(n)]
     procs = []
     for i in range(n):
         env = dict(os.environ)
-        env["HIP_VISIBLE_DEVICES"] = str(i)
+        env["HIP_VISIBLE_DEVICES"] = devices[i]
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-m", "vtc_amd.pipeline.vtc", args.dataset, "--array_id", str(i), "--array_count", str(n)] + rest
         procs.append(subprocess.Popen(cmd, env=env))
