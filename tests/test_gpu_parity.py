@@ -809,7 +809,20 @@ def test_launcher_two_workers_shard_files_and_match_one_process(tmp_path, monkey
                       pq.read_table(out2 / kind / "shard_1.parquet").to_pylist(), key=lambda r: key(r) if "label" in r else r["uid"])
         single = sorted(pq.read_table(out1 / kind / "shard_0.parquet").to_pylist(), key=lambda r: key(r) if "label" in r else r["uid"])
         assert both == single, kind
-    before = {p: p.stat().st_mtime_ns for p in (out2 / "vtc_meta").glob("*.parquet")}
+    # --balance: size-balanced shards (longest-processing-time) instead of equal counts; still a partition, same rows
+    (tmp_path / "manifests" / "bal.csv").write_text("path\n" + "\n".join(names) + "\n")
+    rb = subprocess.run([sys.executable, "-m", "vtc_amd.launcher", "bal", "--devices", "0,0", "--"] + args + ["--balance"],
+                        env=env, capture_output=True, text=True, timeout=170)
+    assert rb.returncode == 0, rb.stdout[-2000:] + rb.stderr[-2000:]
+    outb = tmp_path / "output" / "bal"
+    b0 = pq.read_table(outb / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()
+    b1 = pq.read_table(outb / "vtc_meta" / "shard_1.parquet").column("uid").to_pylist()
+    assert sorted(b0 + b1) == [f"r{k}" for k in range(7)] and not set(b0) & set(b1)
+    size = {f"r{k}": os.path.getsize(names[k]) for k in range(7)}
+    assert abs(sum(size[u] for u in b0) - sum(size[u] for u in b1)) <= max(size.values())       # LPT bound
+    rows_b = sorted(pq.read_table(outb / "vtc_raw" / "shard_0.parquet").to_pylist() +
+                    pq.read_table(outb / "vtc_raw" / "shard_1.parquet").to_pylist(), key=key)
+    assert rows_b == sorted(pq.read_table(out1 / "vtc_raw" / "shard_0.parquet").to_pylist(), key=key)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0 and "0 remaining" in (r.stdout + r.stderr)
     assert sorted(pq.read_table(out2 / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()) == ["r0", "r1", "r2", "r3"]
