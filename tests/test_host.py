@@ -119,6 +119,29 @@ def test_config_and_checkpoint_loading(tmp_path):
     assert tuple(m2.state_dict_host["head.weight"].shape) == (4, 768)
     with pytest.raises(KeyError):
         normalise_state_dict({"foo": np.zeros(3)}, 4)
+    # the same weights under torchaudio's and fairseq's HuBERT names come out under the HF names the engine reads
+    import re
+    hf = {k: v for k, v in synth.make_weights(2).items()}
+    ta = {"wrapped.model." + (re.sub(r"^encoder\.", "encoder.transformer.", k) if k.startswith("encoder.") else
+                              re.sub(r"^feature_projection\.", "encoder.feature_projection.", k)): v
+          for k, v in hf.items() if not k.startswith("head.")}
+    ta["wrapped.heads.weight"], ta["wrapped.heads.bias"] = hf["head.weight"], hf["head.bias"]
+    fs = {}
+    for k, v in hf.items():
+        k = re.sub(r"^feature_extractor\.conv_layers\.(\d+)\.conv\.", r"feature_extractor.conv_layers.\1.0.", k)
+        k = re.sub(r"^feature_extractor\.conv_layers\.0\.layer_norm\.", "feature_extractor.conv_layers.0.2.", k)
+        k = re.sub(r"^feature_projection\.layer_norm\.", "layer_norm.", k)
+        k = re.sub(r"^feature_projection\.projection\.", "post_extract_proj.", k)
+        k = re.sub(r"^encoder\.pos_conv_embed\.conv\.", "encoder.pos_conv.0.", k)
+        k = re.sub(r"\.attention\.", ".self_attn.", k)
+        k = re.sub(r"^(encoder\.layers\.\d+)\.layer_norm\.", r"\1.self_attn_layer_norm.", k)
+        k = re.sub(r"\.feed_forward\.intermediate_dense\.", ".fc1.", k)
+        k = re.sub(r"\.feed_forward\.output_dense\.", ".fc2.", k)
+        fs[("w2v." + k) if not k.startswith("head.") else ("cls." + k[5:])] = v
+    for other in (ta, fs):
+        got = normalise_state_dict(other, 4)
+        assert set(hf) <= set(got), sorted(set(hf) - set(got))[:5]
+        assert all(np.array_equal(got[k], hf[k]) for k in hf)
 
 
 def test_install_as_segma_matches_reference_imports():

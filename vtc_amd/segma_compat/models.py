@@ -54,14 +54,52 @@ def _load_state_dict(path: Path) -> dict:
     return dict(obj)
 
 
+# Other public HuBERT-base layouts, mapped onto the HF names the engine reads (the layout of the real VTC-2.0 checkpoint
+# is unpinned: segma is not in the reference tree).  (pattern, replacement) pairs applied in order to every key.
+_TORCHAUDIO_RULES = (                                 # torchaudio.models.wav2vec2 (hubert_base)
+    (r"^encoder\.feature_projection\.", "feature_projection."),
+    (r"^encoder\.transformer\.", "encoder."),
+)
+_FAIRSEQ_RULES = (                                    # fairseq HubertModel
+    (r"^feature_extractor\.conv_layers\.(\d+)\.0\.", r"feature_extractor.conv_layers.\1.conv."),
+    (r"^feature_extractor\.conv_layers\.0\.2\.", "feature_extractor.conv_layers.0.layer_norm."),
+    (r"^layer_norm\.", "feature_projection.layer_norm."),
+    (r"^post_extract_proj\.", "feature_projection.projection."),
+    (r"^encoder\.pos_conv\.0\.", "encoder.pos_conv_embed.conv."),
+    (r"^encoder\.layers\.(\d+)\.self_attn\.", r"encoder.layers.\1.attention."),
+    (r"^encoder\.layers\.(\d+)\.self_attn_layer_norm\.", r"encoder.layers.\1.layer_norm."),
+    (r"^encoder\.layers\.(\d+)\.fc1\.", r"encoder.layers.\1.feed_forward.intermediate_dense."),
+    (r"^encoder\.layers\.(\d+)\.fc2\.", r"encoder.layers.\1.feed_forward.output_dense."),
+)
+_ANCHORS = (_ANCHOR, "feature_extractor.conv_layers.0.0.weight")
+
+
+def _rename(sd: dict, rules) -> dict:
+    import re
+    out = {}
+    for k, v in sd.items():
+        for pat, rep in rules:
+            k2 = re.sub(pat, rep, k)
+            if k2 != k:
+                k = k2
+                break
+        out[k] = v
+    return out
+
+
 def normalise_state_dict(sd: dict, n_labels: int) -> dict:
-    """Strip whatever wrapper prefix the checkpoint uses and locate the head (UNPINNED: segma's module
-    names are not in the reference tree; HF HubertModel names are what this build understands)."""
-    anchor = [k for k in sd if k.endswith(_ANCHOR)]
+    """Strip whatever wrapper prefix the checkpoint uses, bring torchaudio / fairseq HuBERT names to the HF HubertModel
+    names the engine understands, and locate the head (UNPINNED: segma's module names are not in the reference tree)."""
+    anchor = [(k, a) for a in _ANCHORS for k in sd if k.endswith(a)]
     if not anchor:
         raise KeyError(f"checkpoint has no '*{_ANCHOR}' tensor; not a HuBERT-style encoder")
-    prefix = anchor[0][: -len(_ANCHOR)]
+    key, a = anchor[0]
+    prefix = key[: -len(a)]
     out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if a != _ANCHOR:
+        out = _rename(out, _FAIRSEQ_RULES)
+    elif any(k.startswith("encoder.transformer.") for k in out):
+        out = _rename(out, _TORCHAUDIO_RULES)
     if "head.weight" not in out:
         cands = [k for k, v in sd.items() if k.endswith("weight") and tuple(np.shape(v)) == (n_labels, 768)]
         if len(cands) != 1:
