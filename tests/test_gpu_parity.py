@@ -828,6 +828,56 @@ def test_launcher_two_workers_shard_files_and_match_one_process(tmp_path, monkey
     assert sorted(pq.read_table(out2 / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()) == ["r0", "r1", "r2", "r3"]
 
 
+def test_cli_skewed_manifest_mixed_lengths(weights, tmp_path, monkeypatch):
+    """BASELINE config C5 in small: durations log-uniform from 10 ms (shorter than the receptive field: error row) to
+    minutes, so short files are grouped, long ones run alone, and batches of both kinds alternate in the pipelined GPU
+    thread.  Every file's rows must equal the rows of that file run alone through the engine (windows are independent:
+    bit-exact), in manifest order, with one meta row per file."""
+    from vtc_amd.audio import write_wav
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    rng = np.random.default_rng(55)
+    durs = np.exp(rng.uniform(np.log(0.01), np.log(150.0), 36))
+    durs[[3, 17]] = [0.02, 0.0249]                                  # < 400 samples
+    durs[[5, 6, 7]] = [3.98, 4.0, 4.02]                             # around one window
+    durs[20] = 260.0                                                # many batches on its own
+    names = []
+    for k, d in enumerate(durs):
+        write_wav(tmp_path / "audio" / f"s{k:02d}.wav", synth.synth_audio(float(d), seed=900 + k))
+        names.append(str(tmp_path / "audio" / f"s{k:02d}.wav"))
+    (tmp_path / "manifests" / "skew.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    cli.main("skew", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8, prefetch=3)
+    out = tmp_path / "output" / "skew"
+    seg = pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist()
+    meta = pq.read_table(out / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert [r["uid"] for r in meta] == [f"s{k:02d}" for k in range(len(durs))]               # manifest order, one row each
+    eng = _engine(weights, 4.0, 8)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    from scipy.io import wavfile
+    n_err = 0
+    for k, row in enumerate(meta):
+        uid = row["uid"]
+        _, pcm = wavfile.read(names[k])
+        mine = [(r["onset"], r["offset"], r["duration"], r["label"]) for r in seg if r["uid"] == uid]
+        if len(pcm) < 400:
+            n_err += 1
+            assert "too short" in row["error"] and not mine and row["vtc_n_segments"] == 0
+            continue
+        assert row["error"] == ""
+        logits = eng.infer_waveform(torch.from_numpy(O.pcm_to_mono_float(pcm)).cuda(), batch_size=8).contiguous()
+        s_, e_, l_, mx, mean = eng.decode(logits, lo, hi)
+        want = O.intervals_to_segments([(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s_, e_, l_)], uid)
+        assert mine == [(r["onset"], r["offset"], r["duration"], r["label"]) for r in want], uid
+        ref_row = O.vtc_meta_row(uid, 0.5, want, round(float(torch.sigmoid(torch.tensor(mx, dtype=torch.float32))), 4), round(mean, 4))
+        for key in ("vtc_speech_dur", "vtc_n_segments", "vtc_label_counts", "vtc_max_sigmoid", "vtc_mean_sigmoid"):
+            assert row[key] == ref_row[key], (uid, key)
+    assert n_err >= 2
+    eng.close()
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)

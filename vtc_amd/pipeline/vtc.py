@@ -81,9 +81,16 @@ def _drop_uids(table: pa.Table, uids: set) -> pa.Table:
 
 
 def _unique_rows(table: pa.Table) -> pa.Table:
+    """Drop exact duplicate rows (reference vtc.py:362-365, `seg_df.unique()`), keeping first occurrences in their
+    original order, so the file is deterministic: manifest order, label-major and time-ordered inside a recording."""
     if table.num_rows == 0:
         return table
-    return table.group_by(table.column_names, use_threads=False).aggregate([]).select(table.column_names)
+    names = table.column_names
+    first = table.append_column("__row", pa.array(np.arange(table.num_rows, dtype=np.int64))) \
+        .group_by(names, use_threads=False).aggregate([("__row", "min")]).column("__row_min").to_numpy()
+    if len(first) == table.num_rows:
+        return table
+    return table.take(pa.array(np.sort(first)))
 
 
 def _unique_by_uid_keep_last(table: pa.Table) -> pa.Table:
