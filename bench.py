@@ -127,7 +127,9 @@ def main() -> None:
     rehearse = os.environ.get("VTC_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank %= max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # VTC_BENCH_FORCE_DIST=1 (under torchrun with one rank) runs the RCCL init / barrier / max path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("VTC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo")
@@ -179,7 +181,7 @@ def main() -> None:
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -203,7 +205,7 @@ def main() -> None:
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read() if not args.no_profile else None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -247,7 +249,7 @@ def main() -> None:
             eng.close()
             out["end_to_end_cli"] = end_to_end_cli(args.e2e_files, args.chunk, args.batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
