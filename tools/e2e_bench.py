@@ -37,6 +37,8 @@ def main() -> None:
     ap.add_argument("--prefetch", type=int, default=4)
     ap.add_argument("--format", default="wav", choices=["wav", "flac"], help="container of the generated files (flac: encoded by "
                     "the test encoder of oracle/flac_codec.py, decoded by the library's vtc_flac_decode on the reader threads)")
+    ap.add_argument("--tile", type=int, default=1, help="build each signal by repeating a --seconds/--tile long one (fast "
+                    "generation of day-long files)")
     ap.add_argument("--no_group", action="store_true", help="one forward per file (A/B against cross-file batching)")
     ap.add_argument("--dir", default=None, help="scratch directory (default: a fresh temp dir, /dev/shm if present)")
     args = ap.parse_args()
@@ -45,7 +47,9 @@ def main() -> None:
     (root / "manifests").mkdir(parents=True, exist_ok=True)
     (root / "audio").mkdir(exist_ok=True)
     t0 = time.time()
-    sigs = [synth.synth_audio(args.seconds, seed=1000 + i) for i in range(min(args.distinct, args.files))]
+    sigs = [np.tile(synth.synth_audio(args.seconds / args.tile, seed=1000 + i), args.tile)
+            for i in range(min(args.distinct, args.files))]
+    print(f"signals ready after {time.time() - t0:.1f} s", flush=True)
     paths = []
     if args.format == "flac":
         from oracle import flac_codec           # a tool may use the test encoder to make inputs; the product never does
@@ -57,6 +61,8 @@ def main() -> None:
         else:
             write_wav(p, sigs[i % len(sigs)])
         paths.append(p)
+        if i % 16 == 15 or args.seconds > 3600:
+            print(f"wrote {i + 1}/{args.files} files", flush=True)
     (root / "manifests" / "c2.csv").write_text("path\n" + "\n".join(str(p) for p in paths) + "\n")
     (root / "cfg.yml").write_text(f"model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: {args.chunk}\n")
     gen_s = time.time() - t0
