@@ -189,6 +189,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     def redo(items, e):
         nonlocal n_processed, n_errors
         logger.warning(f"batch of {len(items)} clips failed ({e}); retrying one by one")
+        engine.decode_abandon()
         for item in items:       # a failing batch is retried clip by clip so one bad clip cannot take the others down
             try:
                 seg_blocks.extend(run_group(engine, [item], lo, hi, labels, batch_size))

@@ -873,7 +873,10 @@ int vtc_decode_collect(vtc_model* m, int32_t* out_file, int64_t* out_start, int6
   if (!n_out || (cap > 0 && (!out_file || !out_start || !out_end || !out_label))) return fail(m, VTC_ERR_ARG, "null argument");
   if (!m->dec_active) return fail(m, VTC_ERR_ARG, "vtc_decode_collect without vtc_decode_launch");
   HIP_TRY(m, hipSetDevice(m->device));
-  HIP_TRY(m, hipEventSynchronize(m->dec_event));
+  if (hipError_t e = hipEventSynchronize(m->dec_event); e != hipSuccess) {
+    m->dec_active = false;   // nothing to hand out; do not block later launches
+    return fail(m, VTC_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+  }
   const int nl = m->spec.n_labels, n_files = (int)m->dec_rows.size() - 1;
   const int64_t* rows = m->dec_rows.data();
   const long long n = m->dec_n, rcap = m->dec_rcap;

@@ -244,6 +244,15 @@ class VtcEngine:
         out = (fidx, s, e, lab)
         return out + (mx, mean) if summary else out
 
+    def decode_abandon(self) -> None:
+        """Drop a launched decode whose results are no longer wanted (error paths), so that the next decode_launch()
+        is accepted."""
+        if getattr(self, "_pending_decode", None) is not None:
+            try:
+                self.decode_collect()
+            except Exception:
+                self._pending_decode = None
+
     # ------------------------------------------------------------------ audio front-end
     def prepare_audio(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:
         """Interleaved PCM on the device, int16 or float32, shape (n,) or (n, channels) -> mono float32 at 16 kHz

@@ -396,6 +396,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             _tick("gpu_collect", t_col)
 
         def redo(items, e):
+            engine.decode_abandon()      # a decode left in flight by the failed step must not block the retries
             if len(items) == 1:
                 results[items[0][0]].set_exception(e)
                 return
