@@ -627,6 +627,9 @@ def test_multi_recording_batch_equals_per_recording(weights):
     f1, s1, e1, l1, mx1, mean1 = eng.decode_collect()
     assert not f1.any() and list(s1) == list(ss) and list(e1) == list(se) and list(l1) == list(sl)
     assert float(mx1[0]) == smax and float(mean1[0]) == smean
+    eng.decode_launch(single, [0, single.shape[0]], lo, hi)                    # error paths drop a decode in flight
+    eng.decode_abandon()
+    eng.decode_abandon()                                                       # nothing pending: no-op
     eng.decode_launch(logits.contiguous(), [0, 0, 0], lo, hi, summary=True)   # recordings without rows
     f0, s0, e0, l0, mx0, mean0 = eng.decode_collect()
     assert len(f0) == 0 and list(mean0) == [0.0, 0.0] and np.isneginf(mx0).all()
