@@ -167,6 +167,13 @@ int vtc_flac_info(const void* data /*[host]*/, int64_t n_bytes, int32_t* sample_
                   int32_t* bits_per_sample, int64_t* n_samples, uint8_t* md5 /*[16] or NULL*/);
 int vtc_flac_decode(const void* data /*[host]*/, int64_t n_bytes, void* out /*[host]*/, int32_t out_format,
                     int64_t out_cap, int64_t* n_out);
+/* The same with up to n_threads threads for long streams (day-long recordings: a 16 h file is 8-16 s of work for one
+ * thread): the byte range is cut into pieces of >= 1 MiB, every thread locks onto the first frame that starts in its piece
+ * (header CRC-8 and frame CRC-16 must both check) and places its frames by their coded frame / sample number; pieces
+ * that do not join seamlessly, streams without a declared length and n_threads <= 1 fall back to the sequential decoder,
+ * so the result is always that of vtc_flac_decode. */
+int vtc_flac_decode_threads(const void* data /*[host]*/, int64_t n_bytes, void* out /*[host]*/, int32_t out_format,
+                            int64_t out_cap, int64_t* n_out, int32_t n_threads);
 
 /* Test hook: copy an intermediate activation of the LAST vtc_forward_windows call to the host as fp32.
  * stage: 0..6 conv layer outputs (B,L_i,512); 7 projection (B*T,768); 8 encoder input after pos-conv+LN;

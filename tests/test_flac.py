@@ -216,3 +216,32 @@ def test_decoder_is_thread_safe_and_errors_are_per_thread():
     with ThreadPoolExecutor(max_workers=8) as pool:
         out = list(pool.map(work, range(24)))
     assert out.count("failed as expected") == 8 and out.count("ok") == 16
+
+
+def test_threaded_decode_equals_sequential():
+    """vtc_flac_decode_threads: pieces of a long stream decoded by several threads must give exactly the sequential
+    result -- on noise stored verbatim (the payload is full of byte pairs that look like a frame sync), on a
+    predictor-coded stereo stream, on a variable-block-size stream (frames carry sample numbers) and on a stream
+    without a declared length (sequential fall-back)."""
+    rng = np.random.default_rng(77)
+    noise = rng.integers(-32768, 32768, size=(3_200_000, 1), dtype=np.int64)
+    noise[::4097] = -8          # 0xFFF8: a sync look-alike in every frame, besides the random ones
+    cases = [("verbatim noise", noise, dict(subframe="verbatim", blocksize=4096)),
+             ("coded stereo", tone(1_600_000, 2, 16, seed=9), dict(subframe="fixed2", blocksize=4608, stereo="mid_side")),
+             ("variable blocks", noise[:2_400_000], dict(subframe="verbatim", variable_blocks=[4096, 1152, 576, 4608])),
+             ("no declared length", noise[:1_700_000], dict(subframe="verbatim", blocksize=4096, with_total=False))]
+    lib = L.load()
+    for name, x, kw in cases:
+        enc = F.encode(x, 16000, **kw)
+        assert len(enc) > 3 * (1 << 20), name
+        want, sr = decode_flac(enc, verify_md5=True, n_threads=1)
+        assert np.array_equal(want, as_decoded(x, 16)), name
+        for nt in (2, 3, 5, 64):
+            got, _ = decode_flac(enc, n_threads=nt)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (name, nt)
+        # a damaged frame in the middle is reported, not skipped
+        bad = bytearray(enc)
+        bad[len(bad) // 2] ^= 0x40
+        n, out = C.c_int64(), np.empty((len(x), x.shape[1]), dtype=np.int16)
+        rc = lib.vtc_flac_decode_threads(bytes(bad), len(bad), C.c_void_p(out.ctypes.data), 0, len(x), C.byref(n), 4)
+        assert rc == L.ERR_ARG, name

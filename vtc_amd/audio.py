@@ -80,7 +80,10 @@ def _fast_wav(path: Path):
                 f.seek(size + (size & 1), 1)
 
 
-def decode_flac(data, verify_md5: bool = False):
+FLAC_THREADS = max(1, int(os.environ.get("VTC_FLAC_THREADS", "4")))      # threads per stream of 32 MB or more
+
+
+def decode_flac(data, verify_md5: bool = False, n_threads: int | None = None):
     """FLAC stream held in memory (bytes, bytearray, or a uint8 array / memmap) -> (samples, sample_rate); samples are
     int16 as stored for 16-bit streams (the common case: half the PCIe bytes of float), else float32 = integer /
     2^(bits-1); shape (n,) or (n, channels).  Frame CRCs are always checked; verify_md5 also checks STREAMINFO's MD5
@@ -108,7 +111,9 @@ def decode_flac(data, verify_md5: bool = False):
     else:
         fmt, dtype = 1, np.float32
     out = np.empty((n, ch.value), dtype=dtype)
-    L.check(lib.vtc_flac_decode(ptr, nbytes, C.c_void_p(out.ctypes.data), fmt, n, C.byref(got)))
+    if n_threads is None:
+        n_threads = FLAC_THREADS if buf.size >= (32 << 20) else 1
+    L.check(lib.vtc_flac_decode_threads(ptr, nbytes, C.c_void_p(out.ctypes.data), fmt, n, C.byref(got), int(n_threads)))
     out = out[:got.value]
     if want_md5:
         import hashlib

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -342,8 +343,158 @@ inline bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps, Err
   return true;
 }
 
+// One frame starting at byte `o`: parses and checks the header (CRC-8), decodes the subframes into `block`
+// (channel c at block[c * 65536]), checks the frame CRC-16 and undoes the stereo decorrelation.  On success returns true
+// with the block size, the coded frame / sample number and the byte offset of the next frame.
+struct FrameInfo {
+  int blocksize = 0;
+  bool variable = false;   // blocking strategy: the coded number is a sample number, not a frame number
+  uint64_t number = 0;
+  int64_t next = 0;
+};
+
+inline bool decode_frame(const uint8_t* d, int64_t n, int64_t o, const StreamInfo& si, int64_t* block, FrameInfo& fi, Error& err) {
+  char b[128];
+  if (o + 2 > n || d[o] != 0xff || (d[o + 1] & 0xfe) != 0xf8) {
+    snprintf(b, sizeof b, "lost FLAC frame sync at byte %lld", (long long)o);
+    err.msg = b;
+    return false;
+  }
+  BitReader br(d + o, d + n);
+  br.bits(15);
+  fi.variable = br.bits(1);
+  int bs_code = br.bits(4), sr_code = br.bits(4), ch_code = br.bits(4), ss_code = br.bits(3);
+  if (br.bits(1)) {
+    err.msg = "reserved frame header bit set";
+    return false;
+  }
+  // UTF-8 style coded frame / sample number (up to 36 bits)
+  uint32_t b0 = br.bits(8);
+  int extra = 0;
+  uint64_t num = b0;
+  if (b0 == 0xff) {
+    err.msg = "invalid coded frame number";
+    return false;
+  }
+  if (b0 >= 0xfe) extra = 6, num = 0;
+  else if (b0 >= 0xfc) extra = 5, num = b0 & 0x01;
+  else if (b0 >= 0xf8) extra = 4, num = b0 & 0x03;
+  else if (b0 >= 0xf0) extra = 3, num = b0 & 0x07;
+  else if (b0 >= 0xe0) extra = 2, num = b0 & 0x0f;
+  else if (b0 >= 0xc0) extra = 1, num = b0 & 0x1f;
+  else if (b0 >= 0x80) {
+    err.msg = "invalid coded frame number";
+    return false;
+  }
+  for (int i = 0; i < extra; ++i) {
+    const uint32_t c = br.bits(8);
+    if ((c & 0xc0) != 0x80) {
+      err.msg = "invalid coded frame number";
+      return false;
+    }
+    num = (num << 6) | (c & 0x3f);
+  }
+  fi.number = num;
+  int blocksize;
+  if (bs_code == 0) {
+    err.msg = "reserved block size code";
+    return false;
+  } else if (bs_code == 1) blocksize = 192;
+  else if (bs_code <= 5) blocksize = 576 << (bs_code - 2);
+  else if (bs_code == 6) blocksize = br.bits(8) + 1;
+  else if (bs_code == 7) blocksize = br.bits(16) + 1;
+  else blocksize = 256 << (bs_code - 8);
+  if (sr_code == 12) br.bits(8);
+  else if (sr_code == 13 || sr_code == 14) br.bits(16);
+  else if (sr_code == 15) {
+    err.msg = "invalid sample rate code";
+    return false;
+  }
+  const uint8_t* hdr_end = br.pos();
+  if (hdr_end + 1 > d + n) {
+    err.msg = "truncated FLAC frame header";
+    return false;
+  }
+  if (crc8(d + o, hdr_end) != br.bits(8)) {
+    snprintf(b, sizeof b, "FLAC frame header CRC mismatch at byte %lld", (long long)o);
+    err.msg = b;
+    return false;
+  }
+  int bps;
+  switch (ss_code) {
+    case 0: bps = si.bps; break;
+    case 1: bps = 8; break;
+    case 2: bps = 12; break;
+    case 4: bps = 16; break;
+    case 5: bps = 20; break;
+    case 6: bps = 24; break;
+    case 7: bps = 32; break;
+    default:
+      err.msg = "reserved sample size code";
+      return false;
+  }
+  if (ch_code > 10) {
+    err.msg = "reserved channel assignment";
+    return false;
+  }
+  const int nch = si.channels, frame_ch = ch_code < 8 ? ch_code + 1 : 2;
+  if (frame_ch != nch || bps != si.bps) {
+    err.msg = "channel count or sample size changes inside the stream (not supported)";
+    return false;
+  }
+  for (int c = 0; c < nch; ++c) {
+    int side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
+    if (!read_subframe(br, block + (size_t)c * 65536, blocksize, bps + side, err)) return false;
+  }
+  br.align();
+  const uint8_t* body_end = br.pos();
+  if (body_end + 2 > d + n) {
+    err.msg = "truncated FLAC frame (no CRC)";
+    return false;
+  }
+  if (crc16(d + o, body_end) != (uint16_t)((body_end[0] << 8) | body_end[1])) {
+    snprintf(b, sizeof b, "FLAC frame CRC mismatch at byte %lld", (long long)o);
+    err.msg = b;
+    return false;
+  }
+  int64_t* c0 = block;
+  int64_t* c1 = block + 65536;
+  if (ch_code == 8) {
+    for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+  } else if (ch_code == 9) {
+    for (int i = 0; i < blocksize; ++i) c0[i] = c0[i] + c1[i];
+  } else if (ch_code == 10) {
+    for (int i = 0; i < blocksize; ++i) {
+      int64_t side = c1[i], mid = (int64_t)((uint64_t)c0[i] << 1) | (side & 1);
+      c0[i] = (mid + side) >> 1;
+      c1[i] = (mid - side) >> 1;
+    }
+  }
+  fi.blocksize = blocksize;
+  fi.next = (body_end + 2) - d;
+  return true;
+}
+
+// Interleave `take` samples of a decoded block into the caller's buffer at sample index `at`.
+inline void store_block(const int64_t* block, int nch, int64_t take, void* out, int out_format, int64_t at, float fscale) {
+  for (int c = 0; c < nch; ++c) {
+    const int64_t* src = block + (size_t)c * 65536;
+    if (out_format == 0) {
+      int16_t* dst = (int16_t*)out + at * nch + c;
+      for (int64_t i = 0; i < take; ++i) dst[i * nch] = (int16_t)src[i];
+    } else if (out_format == 1) {
+      float* dst = (float*)out + at * nch + c;
+      for (int64_t i = 0; i < take; ++i) dst[i * nch] = (float)src[i] * fscale;
+    } else {
+      int32_t* dst = (int32_t*)out + at * nch + c;
+      for (int64_t i = 0; i < take; ++i) dst[i * nch] = (int32_t)src[i];
+    }
+  }
+}
+
 // out_format: 0 = int16 (bps <= 16, integers as stored), 1 = float32 (integer / 2^(bps-1)), 2 = int32 (integers as stored).
-// out may be null (count only).  Returns the number of inter-channel samples decoded, or -1.
+// out may be null (count only).  Returns the number of inter-channel samples decoded, -1 on a malformed stream, -2 when
+// the buffer is too small.
 inline int64_t decode(const uint8_t* d, int64_t n, void* out, int out_format, int64_t cap, StreamInfo& si, Error& err) {
   if (!parse_header(d, n, si, err)) return -1;
   if (out_format == 0 && si.bps > 16) {
@@ -358,140 +509,19 @@ inline int64_t decode(const uint8_t* d, int64_t n, void* out, int out_format, in
   while (o < n) {
     // trailing padding / tags after the last frame: stop quietly once the declared total is reached
     if (si.total && done >= si.total) break;
-    if (o + 2 > n || d[o] != 0xff || (d[o + 1] & 0xfe) != 0xf8) {
-      if (si.total == 0 && done > 0) break;  // unknown length: anything that is not a frame ends the stream
-      char b[96];
-      snprintf(b, sizeof b, "lost FLAC frame sync at byte %lld", (long long)o);
-      err.msg = b;
-      return -1;
-    }
-    BitReader br(d + o, d + n);
-    br.bits(16);
-    int bs_code = br.bits(4), sr_code = br.bits(4), ch_code = br.bits(4), ss_code = br.bits(3);
-    if (br.bits(1)) {
-      err.msg = "reserved frame header bit set";
-      return -1;
-    }
-    // UTF-8 style coded frame / sample number
-    uint32_t b0 = br.bits(8);
-    int extra = 0;
-    if (b0 == 0xff) {
-      err.msg = "invalid coded frame number";
-      return -1;
-    }
-    if (b0 >= 0xfe) extra = 6;
-    else if (b0 >= 0xfc) extra = 5;
-    else if (b0 >= 0xf8) extra = 4;
-    else if (b0 >= 0xf0) extra = 3;
-    else if (b0 >= 0xe0) extra = 2;
-    else if (b0 >= 0xc0) extra = 1;
-    else if (b0 >= 0x80) {
-      err.msg = "invalid coded frame number";
-      return -1;
-    }
-    for (int i = 0; i < extra; ++i)
-      if ((br.bits(8) & 0xc0) != 0x80) {
-        err.msg = "invalid coded frame number";
-        return -1;
-      }
-    int blocksize;
-    if (bs_code == 0) {
-      err.msg = "reserved block size code";
-      return -1;
-    } else if (bs_code == 1) blocksize = 192;
-    else if (bs_code <= 5) blocksize = 576 << (bs_code - 2);
-    else if (bs_code == 6) blocksize = br.bits(8) + 1;
-    else if (bs_code == 7) blocksize = br.bits(16) + 1;
-    else blocksize = 256 << (bs_code - 8);
-    if (sr_code == 12) br.bits(8);
-    else if (sr_code == 13 || sr_code == 14) br.bits(16);
-    else if (sr_code == 15) {
-      err.msg = "invalid sample rate code";
-      return -1;
-    }
-    const uint8_t* hdr_end = br.pos();
-    if (hdr_end + 1 > d + n) {
-      err.msg = "truncated FLAC frame header";
-      return -1;
-    }
-    if (crc8(d + o, hdr_end) != br.bits(8)) {
-      char b[96];
-      snprintf(b, sizeof b, "FLAC frame header CRC mismatch at byte %lld", (long long)o);
-      err.msg = b;
-      return -1;
-    }
-    int bps;
-    switch (ss_code) {
-      case 0: bps = si.bps; break;
-      case 1: bps = 8; break;
-      case 2: bps = 12; break;
-      case 4: bps = 16; break;
-      case 5: bps = 20; break;
-      case 6: bps = 24; break;
-      case 7: bps = 32; break;
-      default:
-        err.msg = "reserved sample size code";
-        return -1;
-    }
-    int frame_ch = ch_code < 8 ? ch_code + 1 : 2;
-    if (ch_code > 10) {
-      err.msg = "reserved channel assignment";
-      return -1;
-    }
-    if (frame_ch != nch || bps != si.bps) {
-      err.msg = "channel count or sample size changes inside the stream (not supported)";
-      return -1;
-    }
-    for (int c = 0; c < nch; ++c) {
-      int side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
-      if (!read_subframe(br, block.data() + (size_t)c * 65536, blocksize, bps + side, err)) return -1;
-    }
-    br.align();
-    const uint8_t* body_end = br.pos();
-    if (body_end + 2 > d + n) {
-      err.msg = "truncated FLAC frame (no CRC)";
-      return -1;
-    }
-    if (crc16(d + o, body_end) != (uint16_t)((body_end[0] << 8) | body_end[1])) {
-      char b[96];
-      snprintf(b, sizeof b, "FLAC frame CRC mismatch at byte %lld", (long long)o);
-      err.msg = b;
-      return -1;
-    }
-    o = (body_end + 2) - d;
-    int64_t* c0 = block.data();
-    int64_t* c1 = block.data() + 65536;
-    if (ch_code == 8) {
-      for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
-    } else if (ch_code == 9) {
-      for (int i = 0; i < blocksize; ++i) c0[i] = c0[i] + c1[i];
-    } else if (ch_code == 10) {
-      for (int i = 0; i < blocksize; ++i) {
-        int64_t side = c1[i], mid = (int64_t)((uint64_t)c0[i] << 1) | (side & 1);
-        c0[i] = (mid + side) >> 1;
-        c1[i] = (mid - side) >> 1;
-      }
-    }
-    int64_t take = blocksize;
+    if (si.total == 0 && done > 0 && (o + 2 > n || d[o] != 0xff || (d[o + 1] & 0xfe) != 0xf8))
+      break;  // unknown length: anything that is not a frame ends the stream
+    FrameInfo fi;
+    if (!decode_frame(d, n, o, si, block.data(), fi, err)) return -1;
+    o = fi.next;
+    int64_t take = fi.blocksize;
     if (si.total && done + take > si.total) take = si.total - done;
     if (out) {
       if (done + take > cap) {
         err.msg = "output buffer too small for the FLAC stream";
         return -2;
       }
-      for (int c = 0; c < nch; ++c) {
-        const int64_t* src = block.data() + (size_t)c * 65536;
-        if (out_format == 0) {
-          int16_t* dst = (int16_t*)out + done * nch + c;
-          for (int64_t i = 0; i < take; ++i) dst[i * nch] = (int16_t)src[i];
-        } else if (out_format == 1) {
-          float* dst = (float*)out + done * nch + c;
-          for (int64_t i = 0; i < take; ++i) dst[i * nch] = (float)src[i] * fscale;
-        } else {
-          int32_t* dst = (int32_t*)out + done * nch + c;
-          for (int64_t i = 0; i < take; ++i) dst[i * nch] = (int32_t)src[i];
-        }
-      }
+      store_block(block.data(), nch, take, out, out_format, done, fscale);
     }
     done += take;
   }
@@ -502,6 +532,85 @@ inline int64_t decode(const uint8_t* d, int64_t n, void* out, int out_format, in
     return -1;
   }
   return done;
+}
+
+// Frames are self-contained, so a long stream can be decoded by several threads: the byte range is cut into n_threads
+// pieces, every thread finds the first frame that STARTS in its piece (a candidate must pass the header CRC-8 and decode
+// to a matching frame CRC-16) and decodes frames until one starts in the next piece; a frame's place in the output comes
+// from its coded frame / sample number.  Afterwards the pieces must join seamlessly (byte offsets and sample positions);
+// if they do not (a false sync that survived both CRCs, a stream without a declared length or with a varying nominal
+// block size), the stream is decoded again by the sequential decoder, whose result is the reference.
+inline int64_t decode_parallel(const uint8_t* d, int64_t n, void* out, int out_format, int64_t cap, int n_threads, StreamInfo& si,
+                               Error& err) {
+  if (!parse_header(d, n, si, err)) return -1;
+  const int64_t audio = n - si.audio_offset;
+  if (n_threads > 64) n_threads = 64;
+  while (n_threads > 1 && audio < (int64_t)n_threads * (1 << 20)) --n_threads;   // pieces of at least 1 MiB
+  if (!out || n_threads < 2 || si.total == 0) return decode(d, n, out, out_format, cap, si, err);
+  if (out_format == 0 && si.bps > 16) {
+    err.msg = "int16 output requested for a stream of more than 16 bits per sample";
+    return -1;
+  }
+  if (si.total > cap) {
+    err.msg = "output buffer too small for the FLAC stream";
+    return -2;
+  }
+  struct Piece {
+    int64_t first_byte = -1, end_byte = -1, first_sample = -1, end_sample = -1;
+    bool ok = false;
+  };
+  std::vector<Piece> pieces((size_t)n_threads);
+  const int nch = si.channels;
+  const float fscale = 1.0f / (float)((int64_t)1 << (si.bps - 1));
+  const StreamInfo info = si;
+  auto work = [&](int t) {
+    Piece& pc = pieces[(size_t)t];
+    const int64_t lo = info.audio_offset + audio * t / n_threads, hi = info.audio_offset + audio * (t + 1) / n_threads;
+    std::vector<int64_t> block((size_t)nch * 65536);
+    Error e;
+    FrameInfo fi;
+    int64_t o = lo;
+    if (t > 0) {   // lock onto the first real frame of this piece
+      for (;; ++o) {
+        if (o + 2 > hi) return;   // no frame starts here (pieces are >= 1 MiB, frames <= ~0.5 MiB: does not happen)
+        if (d[o] != 0xff || (d[o + 1] & 0xfe) != 0xf8) continue;
+        if (decode_frame(d, n, o, info, block.data(), fi, e)) break;
+      }
+    } else if (!decode_frame(d, n, o, info, block.data(), fi, e)) {
+      return;
+    }
+    pc.first_byte = o;
+    for (;;) {
+      const int64_t at = fi.variable ? (int64_t)fi.number : (int64_t)fi.number * info.min_block;
+      if (pc.first_sample < 0) pc.first_sample = at;
+      else if (at != pc.end_sample) return;       // numbering is not contiguous: leave it to the sequential decoder
+      if (at >= info.total) return;
+      int64_t take = fi.blocksize;
+      if (at + take > info.total) take = info.total - at;
+      store_block(block.data(), nch, take, out, out_format, at, fscale);
+      pc.end_sample = at + take;
+      o = fi.next;
+      pc.end_byte = o;
+      if (o >= hi || pc.end_sample >= info.total) break;
+      if (!decode_frame(d, n, o, info, block.data(), fi, e)) return;
+    }
+    pc.ok = true;
+  };
+  std::vector<std::thread> threads;
+  for (int t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+  work(0);
+  for (auto& th : threads) th.join();
+  bool good = pieces[0].ok && pieces[0].first_sample == 0;
+  int64_t last_end = pieces[0].end_sample;
+  for (int t = 1; good && t < n_threads; ++t) {
+    const Piece& a = pieces[(size_t)t - 1];
+    const Piece& b = pieces[(size_t)t];
+    if (a.end_sample >= si.total && !b.ok && b.first_byte < 0) continue;   // stream ended inside an earlier piece (trailing tags)
+    good = b.ok && b.first_byte == a.end_byte && b.first_sample == a.end_sample;
+    if (good) last_end = b.end_sample;
+  }
+  if (good && last_end == si.total) return si.total;
+  return decode(d, n, out, out_format, cap, si, err);   // anything unusual: the sequential decoder decides
 }
 
 }  // namespace flac

@@ -1089,11 +1089,17 @@ int vtc_flac_info(const void* data, int64_t n_bytes, int32_t* sample_rate, int32
 }
 
 int vtc_flac_decode(const void* data, int64_t n_bytes, void* out, int32_t out_format, int64_t out_cap, int64_t* n_out) {
+  return vtc_flac_decode_threads(data, n_bytes, out, out_format, out_cap, n_out, 1);
+}
+
+int vtc_flac_decode_threads(const void* data, int64_t n_bytes, void* out, int32_t out_format, int64_t out_cap, int64_t* n_out,
+                            int32_t n_threads) {
   if (!data || n_bytes < 0 || !n_out) return fail(nullptr, VTC_ERR_ARG, "null argument");
   if (out_format < 0 || out_format > 2) return fail(nullptr, VTC_ERR_ARG, "out_format must be 0 (int16), 1 (float32) or 2 (int32)");
   flac::StreamInfo si;
   flac::Error err;
-  const int64_t got = flac::decode((const uint8_t*)data, n_bytes, out, out_format, out_cap, si, err);
+  const int64_t got = n_threads > 1 ? flac::decode_parallel((const uint8_t*)data, n_bytes, out, out_format, out_cap, n_threads, si, err)
+                                    : flac::decode((const uint8_t*)data, n_bytes, out, out_format, out_cap, si, err);
   if (got == -2) return fail(nullptr, VTC_ERR_CAPACITY, "%s", err.msg.c_str());
   if (got < 0) return fail(nullptr, VTC_ERR_ARG, "%s", err.msg.c_str());
   *n_out = got;
