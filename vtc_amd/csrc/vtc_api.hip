@@ -117,8 +117,13 @@ int fail(vtc_model* m, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (m) m->err = buf;
-  else g_create_error = buf;
+  if (m) {
+    static std::mutex mu;   // vtc_prepare_audio may fail on several reader threads at once
+    std::lock_guard<std::mutex> lock(mu);
+    m->err = buf;
+  } else {
+    g_create_error = buf;
+  }
   return code;
 }
 
