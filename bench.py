@@ -6,8 +6,12 @@ synthetic 16 kHz audio (already resident in HBM) -> BabyHuBERT forward -> stitch
 threshold/run-length decode to (start, end, label) triples on the host.  Workload at N=1 is
 BASELINE.json configs[1]: fixed 10 s windows, batch 64, 16-bit MFMA transformer.
 
-N > 1: one process per GPU (torch.distributed launch), files/windows are sharded, no collective in the
-data path; the only communication is the timing barrier + max-over-ranks.
+N > 1: one process per GPU, files/windows are sharded, no collective in the data path (the
+reference runs one process per GPU as a SLURM array, slurm/vtc.slurm:9-10); the only communication is the timing
+barrier + max-over-ranks.  The ranks come either from an external launcher (torch.distributed.run sets WORLD_SIZE /
+RANK / LOCAL_RANK) or, when WORLD_SIZE is unset and --gpus N > 1, from this script itself: the parent starts N fresh
+child processes before it touches the GPU, waits for them and exits with their status; it never initialises HIP.
+`n_gpus` in the JSON line is the size of the initialised process group, not the flag.
 """
 
 from __future__ import annotations
@@ -67,7 +71,7 @@ def cpu_baseline(chunk_s: float, n_windows: int, batch: int) -> dict:
     """The fp32 CPU oracle (oracle/vtc_oracle.py) timed on this host's cores on a bounded sample."""
     from oracle import vtc_oracle as O
     threads = torch.get_num_threads()
-    w = O.make_weights(seed=0)
+    w = O.make_weights(seed=0, family="hubert", calibrated=True)
     W = int(round(chunk_s * 16000))
     T = O.conv_out_len(W)
     audio = synth.synth_audio((n_windows * T * 320 + W) / 16000.0, seed=1000)
@@ -101,6 +105,62 @@ def end_to_end_cli(n_files: int, chunk_s: float, batch: int) -> dict:
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), forward
+    their output, and return the worst exit status.  Runs before any GPU call: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VTC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:      # one rank failed: the others would wait at the barrier forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def spawn_check() -> None:
+    """--spawn-check: the N > 1 plumbing alone (rendezvous, barrier, max over ranks, the rank-0 line) with no GPU work;
+    tests/test_host.py runs it over gloo with two ranks."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n, worst = dist.get_world_size(), float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        n, worst = 1, 1.0
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": n, "max_over_ranks": worst,
+                          "spawned_by_bench": os.environ.get("VTC_BENCH_SPAWNED") == "1"}), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +177,14 @@ def main() -> None:
     ap.add_argument("--profile-every", type=int, default=10,
                     help="steps of the timed region whose launches are bracketed by HIP events: every n-th (two event "
                          "records per launch cost ~7 us of stream time, ~0.75 ms per fully profiled step)")
+    ap.add_argument("--spawn-check", action="store_true", help="only exercise the N > 1 launch plumbing (no GPU work)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))     # the parent never touches the GPU
+    if args.spawn_check:
+        spawn_check()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,10 +202,11 @@ def main() -> None:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        world = dist.get_world_size()      # what the initialised group reports, not the flag
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    weights = synth.make_weights(seed=0)
+    weights = synth.make_weights(seed=0, family="hubert", calibrated=True)   # HuBERT-base init, logit std 2
     eng = VtcEngine(weights, n_labels=4, chunk_duration_s=args.chunk, max_batch=args.batch, mfma_dtype=args.dtype,
                     device=dev)
     T, W, step = eng.frames_per_window, eng.window_samples, eng.step
@@ -219,7 +287,7 @@ def main() -> None:
             "metric": "VTC audio-hours/sec (node)", "value": value, "unit": "audio-hours/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic (seeded harmonic bursts + noise; seeded random BabyHuBERT-base weights)",
+            "data": "synthetic (seeded harmonic bursts + noise; seeded HuBERT-base-initialised weights, head calibrated to logit std 2)",
             "config": {"workload": f"BASELINE configs[1]: fixed {args.chunk:g} s windows ({W} samples -> {T} frames), "
                                    f"batch {args.batch}, forward + threshold/run-length decode, inputs resident in HBM",
                        "batch_windows": args.batch, "chunk_duration_s": args.chunk, "frames_per_window": T,

@@ -112,56 +112,18 @@ def plan_windows(n_samples: int, chunk_duration_s: float) -> WindowPlan:
 
 
 # --------------------------------------------------------------------------- weights
-def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0) -> dict:
-    """Seeded random BabyHuBERT-shaped weights (real VTC-2.0 checkpoint is absent offline).
+def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, family: str = "stress",
+                 calibrated: bool = False) -> dict:
+    """Seeded random BabyHuBERT-shaped weights (the real VTC-2.0 checkpoint is absent offline) as torch tensors.
 
-    numpy PCG64 so the same seed gives the same tensors on every machine.  Scales are
-    1/sqrt(fan_in) (not HF's 0.02) so attention/FFN branches carry as much signal as the
-    residual stream: a harder numerical test for the bf16 path.  Names follow the HF state
-    dict so the same dict can be loaded into transformers.HubertModel for pinning.
-    """
-    rng = np.random.default_rng(seed)
-
-    def randn(*shape, std=1.0):
-        return torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(std)))
-
-    w = {}
-    cin = 1
-    for i, k in enumerate(CONV_KERNELS):
-        w[f"feature_extractor.conv_layers.{i}.conv.weight"] = randn(512, cin, k, std=(2.0 / (cin * k)) ** 0.5)
-        cin = 512
-    w["feature_extractor.conv_layers.0.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
-    w["feature_extractor.conv_layers.0.layer_norm.bias"] = randn(512, std=0.1)
-    w["feature_projection.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
-    w["feature_projection.layer_norm.bias"] = randn(512, std=0.1)
-    w["feature_projection.projection.weight"] = randn(768, 512, std=512 ** -0.5)
-    w["feature_projection.projection.bias"] = randn(768, std=0.02)
-    # positional conv: weight-norm parametrisation (dim=2): g [1,1,128], v [768,48,128]
-    v = randn(768, 48, 128, std=(48 * 128) ** -0.5)
-    w["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
-    w["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (
-        v.double().pow(2).sum(dim=(0, 1), keepdim=True).sqrt().float() * (1.0 + randn(1, 1, 128, std=0.1))
-    )
-    w["encoder.pos_conv_embed.conv.bias"] = randn(768, std=0.02)
-    w["encoder.layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-    w["encoder.layer_norm.bias"] = randn(768, std=0.1)
-    for l in range(12):
-        p = f"encoder.layers.{l}."
-        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            w[p + f"attention.{nm}.weight"] = randn(768, 768, std=768 ** -0.5)
-            w[p + f"attention.{nm}.bias"] = randn(768, std=0.02)
-        w[p + "layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-        w[p + "layer_norm.bias"] = randn(768, std=0.1)
-        w[p + "feed_forward.intermediate_dense.weight"] = randn(3072, 768, std=768 ** -0.5)
-        w[p + "feed_forward.intermediate_dense.bias"] = randn(3072, std=0.02)
-        w[p + "feed_forward.output_dense.weight"] = randn(768, 3072, std=3072 ** -0.5)
-        w[p + "feed_forward.output_dense.bias"] = randn(768, std=0.02)
-        w[p + "final_layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-        w[p + "final_layer_norm.bias"] = randn(768, std=0.1)
-    # "hydra" head: one linear unit per label on the last hidden state (UNPINNED topology).
-    w["head.weight"] = randn(n_labels, 768, std=logit_std * 768 ** -0.5)
-    w["head.bias"] = randn(n_labels, std=0.5)
-    return w
+    The tensors are INPUT DATA shared with the HIP path, so there is one generator: vtc_amd.synth.make_weights (numpy
+    PCG64, the same tensors on every machine; families "stress" = 1/sqrt(fan_in) scales and "hubert" = the HuBERT-base
+    initialisation of SURVEY.md 8d; calibrated=True applies the committed head scale of tests/golden/head_calibration.json).
+    Names follow the HF state dict so the same dict can be loaded into transformers.HubertModel for pinning; the
+    "hydra" head is one linear unit per label on the last hidden state (UNPINNED topology)."""
+    from vtc_amd import synth
+    w = synth.make_weights(seed=seed, n_labels=n_labels, logit_std=logit_std, family=family, calibrated=calibrated)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
 
 
 def pos_conv_weight(w: dict) -> torch.Tensor:

@@ -336,6 +336,27 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert all(o["slowest"] == 2.0 and o["total"] == 11 for o in outs)
 
 
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank processes by itself (the parent
+    never touches the GPU) and rank 0 must report the size of the initialised group.  --spawn-check runs the launch
+    plumbing (rendezvous on 127.0.0.1, barrier, max over ranks) over gloo with no GPU work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # only rank 0 prints
+    assert lines[0] == {"spawn_check": True, "n_gpus": 2, "max_over_ranks": 2.0, "spawned_by_bench": True}
+    # under an external launcher (WORLD_SIZE set) the script is a rank and starts nothing
+    r1 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--spawn-check"],
+                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["spawned_by_bench"] is False
+    # a failing rank ends the run with a non-zero status instead of leaving the others at the barrier
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dtype", "nonsense"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0
+
+
 def test_host_resampler_matches_oracle_restatement_of_torchaudio():
     """audio.sinc_resample (host form of the GPU front-end) vs oracle.resample_sinc_hann (torchaudio's published
     algorithm restated with torch ops); lengths are ceil(n * 16000 / sr)."""

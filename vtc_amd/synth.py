@@ -50,47 +50,81 @@ def synth_audio(duration_s: float, seed: int, dtype=np.float32) -> np.ndarray:
     return (out + noise).astype(dtype)
 
 
-def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0) -> dict:
+def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, family: str = "stress",
+                 calibrated: bool = False) -> dict:
     """Seeded random weights under HF HubertModel state-dict names (+ head.weight / head.bias).
-    numpy PCG64 -> identical tensors on every machine.  Scales are 1/sqrt(fan_in) so every branch
-    carries signal (a harder numerical case than HF's 0.02 init)."""
+    numpy PCG64 -> identical tensors on every machine.
+
+    family "stress": every scale is 1/sqrt(fan_in), LayerNorm affine 1 +- 0.1 / +- 0.1, so the attention and FFN branches
+        carry as much signal as the residual stream (a harder numerical case than a HuBERT init: deep random post-LN
+        stacks of this kind collapse the frames onto one direction, so the logits move little around a common offset).
+    family "hubert": the HuBERT-base initialisation SURVEY.md 8(d) prescribes (transformers HubertPreTrainedModel.
+        _init_weights with initializer_range 0.02: Linear N(0, 0.02) / bias 0, LayerNorm and GroupNorm 1 / 0, Conv1d
+        kaiming-normal, weight-norm g = ||v||).
+    calibrated: scale head.weight and head.bias by the committed factor (HEAD_CALIBRATION, made by tests/golden/make_head_calibration.py
+        with the CPU oracle) that brings the oracle's logit std on the calibration clip to `logit_std` = 2 (SURVEY.md 8d:
+        "head scaled so logit std ~ 2")."""
+    if family not in ("stress", "hubert"):
+        raise ValueError(f"unknown weight family {family!r}")
     rng = np.random.default_rng(seed)
+    hub = family == "hubert"
 
     def randn(*shape, std=1.0):
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+
+    def affine(n):    # LayerNorm / GroupNorm weight, bias (the draws are made in both families: same stream positions)
+        a, b = randn(n, std=0.1), randn(n, std=0.1)
+        return (np.ones(n, np.float32), np.zeros(n, np.float32)) if hub else (1.0 + a, b)
+
+    def bias(n, std=0.02):
+        b = randn(n, std=std)
+        return np.zeros(n, np.float32) if hub else b
+
+    def lin(n, k):
+        return randn(n, k, std=0.02 if hub else k ** -0.5)
 
     w = {}
     cin = 1
     for i, k in enumerate(CONV_KERNELS):
         w[f"feature_extractor.conv_layers.{i}.conv.weight"] = randn(512, cin, k, std=(2.0 / (cin * k)) ** 0.5)
         cin = 512
-    w["feature_extractor.conv_layers.0.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
-    w["feature_extractor.conv_layers.0.layer_norm.bias"] = randn(512, std=0.1)
-    w["feature_projection.layer_norm.weight"] = 1.0 + randn(512, std=0.1)
-    w["feature_projection.layer_norm.bias"] = randn(512, std=0.1)
-    w["feature_projection.projection.weight"] = randn(768, 512, std=512 ** -0.5)
-    w["feature_projection.projection.bias"] = randn(768, std=0.02)
-    v = randn(768, 48, 128, std=(48 * 128) ** -0.5)
+    (w["feature_extractor.conv_layers.0.layer_norm.weight"],
+     w["feature_extractor.conv_layers.0.layer_norm.bias"]) = affine(512)
+    w["feature_projection.layer_norm.weight"], w["feature_projection.layer_norm.bias"] = affine(512)
+    w["feature_projection.projection.weight"] = lin(768, 512)
+    w["feature_projection.projection.bias"] = bias(768)
+    v = randn(768, 48, 128, std=(2.0 if hub else 1.0) ** 0.5 * (48 * 128) ** -0.5)
     w["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
+    g = randn(1, 1, 128, std=0.1)
     w["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (
         np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
-        * (1.0 + randn(1, 1, 128, std=0.1)))
-    w["encoder.pos_conv_embed.conv.bias"] = randn(768, std=0.02)
-    w["encoder.layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-    w["encoder.layer_norm.bias"] = randn(768, std=0.1)
+        * (np.float32(1.0) if hub else (1.0 + g)))
+    w["encoder.pos_conv_embed.conv.bias"] = bias(768)
+    w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"] = affine(768)
     for l in range(12):
         p = f"encoder.layers.{l}."
         for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            w[p + f"attention.{nm}.weight"] = randn(768, 768, std=768 ** -0.5)
-            w[p + f"attention.{nm}.bias"] = randn(768, std=0.02)
-        w[p + "layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-        w[p + "layer_norm.bias"] = randn(768, std=0.1)
-        w[p + "feed_forward.intermediate_dense.weight"] = randn(3072, 768, std=768 ** -0.5)
-        w[p + "feed_forward.intermediate_dense.bias"] = randn(3072, std=0.02)
-        w[p + "feed_forward.output_dense.weight"] = randn(768, 3072, std=3072 ** -0.5)
-        w[p + "feed_forward.output_dense.bias"] = randn(768, std=0.02)
-        w[p + "final_layer_norm.weight"] = 1.0 + randn(768, std=0.1)
-        w[p + "final_layer_norm.bias"] = randn(768, std=0.1)
+            w[p + f"attention.{nm}.weight"] = lin(768, 768)
+            w[p + f"attention.{nm}.bias"] = bias(768)
+        w[p + "layer_norm.weight"], w[p + "layer_norm.bias"] = affine(768)
+        w[p + "feed_forward.intermediate_dense.weight"] = lin(3072, 768)
+        w[p + "feed_forward.intermediate_dense.bias"] = bias(3072)
+        w[p + "feed_forward.output_dense.weight"] = lin(768, 3072)
+        w[p + "feed_forward.output_dense.bias"] = bias(768)
+        w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"] = affine(768)
     w["head.weight"] = randn(n_labels, 768, std=logit_std * 768 ** -0.5)
     w["head.bias"] = randn(n_labels, std=0.5)
+    if calibrated:
+        key = f"{family}:{seed}"
+        if n_labels != 4 or key not in HEAD_CALIBRATION:
+            raise ValueError(f"no committed head calibration for {key} with {n_labels} labels")
+        scale = np.float32(logit_std / HEAD_CALIBRATION[key])
+        w["head.weight"] = w["head.weight"] * scale
+        w["head.bias"] = w["head.bias"] * scale
     return w
+
+
+# Oracle logit std of the uncalibrated weights on the calibration clip (synth_audio(40 s, seed 9000), 10 s windows, full
+# windows only); written by tests/golden/make_head_calibration.py, which also commits tests/golden/head_calibration.json.
+HEAD_CALIBRATION: dict = {"stress:0": 0.864546, "stress:1": 2.370401, "stress:2": 0.574449, "stress:3": 2.047762,
+                          "hubert:0": 2.250636, "hubert:1": 2.099057, "hubert:2": 1.722512, "hubert:3": 2.136115}
