@@ -31,7 +31,8 @@ typedef enum {
   VTC_ERR_HIP = -2,       /* a HIP runtime call failed */
   VTC_ERR_NO_GPU = -3,    /* no gfx950 device visible */
   VTC_ERR_CAPACITY = -4,  /* caller buffer too small; the needed size is reported */
-  VTC_ERR_SHORT = -5      /* audio shorter than the 400-sample receptive field */
+  VTC_ERR_SHORT = -5,     /* audio shorter than the 400-sample receptive field */
+  VTC_ERR_NONFINITE = -6  /* NaN / inf logits: an activation left the range of the 16-bit storage type upstream */
 } vtc_status;
 
 typedef struct vtc_model vtc_model; /* opaque */
@@ -101,11 +102,20 @@ int vtc_infer_waveform(vtc_model* m, const float* wav /*[dev]*/, int64_t n_sampl
  * summary (vtc.py:266-273).  Frame f of label l is active iff lo_logit[l] <= logits[f][l] <= hi_logit[l].
  * Every run of active frames i..j yields out_start = i*320, out_end = j*320+400 (samples), out_label = l;
  * output is label-major, time-ordered.  Synchronises `stream` before returning.
- * On VTC_ERR_CAPACITY *n_out holds the number of intervals needed. */
+ * On VTC_ERR_CAPACITY *n_out holds the number of intervals needed.
+ * A NaN compares false against every bound, so non-finite logits would decode as "inactive" and the recording would
+ * look valid: if any logit of the rows is NaN or +-inf the call fails with VTC_ERR_NONFINITE instead (the host writes an
+ * error row, src/pipeline/vtc.py:245-249).  The f16 kernels store activations in fp16; values beyond 65504 become inf
+ * there and reach the logits as NaN. */
 int vtc_decode(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,
                const float* hi_logit /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,
                int32_t* out_label /*[host]*/, int64_t cap, int64_t* n_out, float* max_logit, double* mean_sigmoid,
                void* stream);
+
+/* Stands behind: segma.inference.apply_thresholds alone (vtc.py:84-90), for callers that look at the 0/1 mask itself:
+ * mask[f * n_labels + l] = (lo_logit[l] <= logits[f][l] <= hi_logit[l]) ? 1 : 0.  Asynchronous on `stream`. */
+int vtc_threshold_mask(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,
+                       const float* hi_logit /*[host]*/, uint8_t* mask /*[dev] n_frames x n_labels*/, void* stream);
 
 /* Several recordings in one call (second caller of the boundary: src/analysis/vtc_on_clips.py:154-211 runs
  * apply_model_on_audio once per packaged clip, most of them shorter than a batch of windows).  Recording f is
@@ -119,7 +129,10 @@ int vtc_infer_waveforms(vtc_model* m, const float* wav /*[dev]*/, const int64_t*
 /* vtc_decode over such a row layout: runs never cross a recording boundary, out_start / out_end are samples relative
  * to the recording, output is recording-major and inside a recording label-major, time-ordered (= vtc_decode on each
  * recording's rows).  max_logit / mean_sigmoid (each [n_files], may be null) receive the per-recording sigmoid
- * summary of src/pipeline/vtc.py:266-273.  Synchronises `stream`. */
+ * summary of src/pipeline/vtc.py:266-273.  Synchronises `stream`.
+ * Non-finite logits: max_logit[f] is NaN for exactly the recordings that hold a NaN / inf logit (their runs are not to be
+ * trusted; the other recordings are unaffected); without max_logit the call fails with VTC_ERR_NONFINITE if any row is
+ * affected.  vtc_decode_collect follows the same rule (want_summary set: NaN marks; not set: the error). */
 int vtc_decode_files(vtc_model* m, const float* logits /*[dev]*/, const int64_t* file_rows /*[host] n_files+1*/,
                      int32_t n_files, const float* lo_logit /*[host]*/, const float* hi_logit /*[host]*/,
                      int32_t* out_file /*[host]*/, int64_t* out_start /*[host]*/, int64_t* out_end /*[host]*/,

@@ -333,6 +333,88 @@ def test_decode_bit_exact_against_oracle(weights):
     eng.close()
 
 
+def test_many_one_frame_recordings_all_active(weights):
+    """Runs are split at recording boundaries, so n frames in f recordings can hold up to (n + f) / 2 runs per label:
+    2000 one-frame recordings, every frame active, give 2000 runs per label from 2000 frames (more than n / 2 + 1)."""
+    eng = _engine(weights, 1.0, 1)
+    n = 2000
+    logits = torch.full((n, 4), 2.0, device="cuda")
+    rows = np.arange(n + 1, dtype=np.int64)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    want_file = np.repeat(np.arange(n), 4)
+    want_lab = np.tile(np.arange(4), n)
+    for call in ("files", "launch"):
+        if call == "files":
+            fidx, s, e, lab, mx, mean = eng.decode_files(logits, rows, lo, hi, summary=True)
+        else:
+            eng.decode_launch(logits, rows, lo, hi, summary=True)
+            fidx, s, e, lab, mx, mean = eng.decode_collect()
+        assert len(s) == 4 * n
+        assert np.array_equal(fidx, want_file) and np.array_equal(lab, want_lab)
+        assert np.all(s == 0) and np.all(e == 400)
+        assert np.all(mx == 2.0) and np.allclose(mean, 1 / (1 + math.exp(-2.0)))
+    # mixed: recordings of 1..3 frames with alternating activity, against the per-recording oracle
+    rng = np.random.default_rng(8)
+    lens = rng.integers(1, 4, size=700)
+    rows = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    host = np.where(rng.random((int(rows[-1]), 4)) < 0.6, 1.5, -1.5).astype(np.float32)
+    fidx, s, e, lab = eng.decode_files(torch.from_numpy(host).cuda(), rows, lo, hi)
+    have = [(int(f), int(a), int(b), O.DEFAULT_LABELS[int(c)]) for f, a, b, c in zip(fidx, s, e, lab)]
+    want = []
+    for f in range(len(lens)):
+        m = O.apply_thresholds(torch.from_numpy(host[rows[f]:rows[f + 1]]), THR)
+        want += [(f, a, b, l) for a, b, l in O.create_intervals(m)]
+    assert have == want
+    eng.close()
+
+
+def test_non_finite_logits_are_an_error_not_silence(weights):
+    """fp16 storage overflows at 65504; an inf there reaches the logits as NaN, and NaN compares false against every
+    bound: without a guard the recording would decode as 'no speech'.  The decode must fail (single recording) or
+    mark exactly the affected recordings (several), and the host turns that into an error row."""
+    from vtc_amd.pipeline import vtc as cli
+    eng = _engine(weights, 1.0, 2)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    host = np.random.default_rng(4).standard_normal((600, 4)).astype(np.float32)
+    host[250, 2] = np.nan
+    host[460, 0] = np.inf
+    dev = torch.from_numpy(host).cuda()
+    with pytest.raises(lib.VtcError) as ei:
+        eng.decode(dev, lo, hi)
+    assert ei.value.status == lib.ERR_NONFINITE and "non-finite" in str(ei.value)
+    rows = np.array([0, 200, 300, 450, 600], dtype=np.int64)     # recordings 1 and 3 are affected
+    for call in ("files", "launch"):
+        if call == "files":
+            fidx, s, e, lab, mx, mean = eng.decode_files(dev, rows, lo, hi, summary=True)
+        else:
+            eng.decode_launch(dev, rows, lo, hi, summary=True)
+            fidx, s, e, lab, mx, mean = eng.decode_collect()
+        assert [bool(np.isnan(v)) for v in mx] == [False, True, False, True]
+        for f in (0, 2):     # untouched recordings: same runs as decoded alone
+            a, b, c, _, _ = eng.decode(dev[rows[f]:rows[f + 1]].contiguous(), lo, hi)
+            sel = fidx == f
+            assert np.array_equal(s[sel], a) and np.array_equal(e[sel], b) and np.array_equal(lab[sel], c)
+    with pytest.raises(lib.VtcError):
+        eng.decode_files(dev, rows, lo, hi)          # no summary asked for: nothing could carry the mark
+    eng.decode_launch(dev, rows, lo, hi)
+    with pytest.raises(lib.VtcError):
+        eng.decode_collect()
+    eng.decode_launch(dev[:200].contiguous(), np.array([0, 200]), lo, hi)     # the engine is usable again afterwards
+    assert len(eng.decode_collect()[1]) > 0
+    eng.close()
+    # a weight set that drives the FFN hidden state past 65504: the forward itself yields NaN logits
+    w = dict(weights)
+    key = "encoder.layers.5.feed_forward.intermediate_dense.weight"
+    w[key] = w[key] * 1.0e5
+    big = _engine(w, 1.0, 2)
+    wav = synth.synth_audio(2.5, seed=3)
+    got = big.infer_waveform(torch.from_numpy(wav).cuda())
+    assert not torch.isfinite(got).all()
+    with pytest.raises(ValueError, match="non-finite"):
+        cli.process_file(big, wav, "loud", 0.5, list(O.DEFAULT_LABELS), 2, None)
+    big.close()
+
+
 @pytest.mark.parametrize("n_labels", [1, 3, 8])
 def test_other_label_counts(n_labels):
     """The head width is data (cfg.data.classes, SURVEY 8c: label set unpinned): 1, 3 and the maximum of 8 labels
@@ -385,9 +467,33 @@ def test_reference_host_flow_through_segma_surface(weights, tmp_path):
                                  device="cuda", batch_size=128, chunk_duration_s=cfg.audio.chunk_duration_s)
     assert torch.equal(logits_t, again)
     cpu = logits_t.cpu()
-    thresholded = apply_thresholds(cpu, {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in enc.labels}, "cpu").detach()
+    thr = {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in enc.labels}
+    thresholded = apply_thresholds(cpu, thr, "cpu").detach()
+    # a real 0/1 tensor the caller can look at ("apply_thresholds(logits, dict, 'cpu') -> Tensor")
+    assert isinstance(thresholded, torch.Tensor) and thresholded.dtype == torch.uint8 and thresholded.device.type == "cpu"
+    assert torch.equal(thresholded, O.apply_thresholds(cpu, THR))
+    assert thresholded.float().mean().item() == O.apply_thresholds(cpu, THR).float().mean().item()
     intervals = create_intervals(thresholded, model.conv_settings, enc)
     assert intervals == O.create_intervals(O.apply_thresholds(cpu, THR))
+    # plain tensors made by the caller work too: logits without provenance, and a mask changed after the fact
+    plain = cpu.clone().as_subclass(torch.Tensor)
+    assert torch.equal(apply_thresholds(plain, thr, "cpu"), thresholded)
+    edited = thresholded.clone()
+    edited[:, 1] = 0
+    edited[5:9, 2] = 1
+    assert create_intervals(edited, model.conv_settings, enc) == O.create_intervals(edited.numpy())
+    in_place = apply_thresholds(cpu, thr, "cpu")
+    in_place[:, 0] = 0                       # the carried device logits no longer describe this mask
+    assert create_intervals(in_place, model.conv_settings, enc) == O.create_intervals(in_place.numpy())
+    # two models alive at once: each mask decodes on the engine that made its logits
+    enc2 = MultiLabelEncoder(labels=["A", "B"])
+    model2 = Models["hydra"].load_from_checkpoint(checkpoint_path="synthetic:3", label_encoder=enc2, config=cfg, train=False)
+    l2 = apply_model_on_audio(audio_path=tmp_path / "a.wav", model=model2.to(torch.device("cuda")),
+                              conv_settings=model2.conv_settings, device="cuda", batch_size=8, chunk_duration_s=2.0)
+    m2 = apply_thresholds(l2.cpu(), {l: {"lower_bound": 0.4, "upper_bound": 1.0} for l in enc2.labels}, "cpu")
+    assert m2.shape == (l2.shape[0], 2)
+    assert create_intervals(m2, model2.conv_settings, enc2) == O.create_intervals(m2.numpy(), labels=("A", "B"))
+    assert create_intervals(thresholded, model.conv_settings, enc) == intervals
     from vtc_amd.audio import read_audio
     ref = O.apply_model_on_waveform(weights, read_audio(tmp_path / "a.wav"), 4.0)
     assert (cpu - ref).abs().max().item() <= LOGIT_TOL

@@ -1,0 +1,68 @@
+"""BASELINE.json north_star tolerances on the C1 workload (configs[0]: one 10-minute 16 kHz recording), HIP path against
+the fp32 CPU oracle, asserted unconditionally:
+
+    per-frame logits within 2e-2 abs;  per-frame label agreement >= 99.9 %;  segment onset / offset within one 20 ms frame
+    (fraction of segments with both boundaries within one frame, on vtc_raw and on the collar-merged vtc_merged table).
+
+Weights: SURVEY.md 8(d) prescribes "seeded random HuBERT-base init + head scaled so logit std ~ 2"; that is
+synth.make_weights(family="hubert", calibrated=True) (the measured std of every seed is committed in
+tests/golden/head_calibration.json).  The second family ("stress": 1/sqrt(fan_in) scales everywhere) is an adversarial case
+this repo adds on its own: deep random post-LN stacks of that kind collapse all frames onto one direction, the logits of a
+label then sit in a narrow band around a common offset, and calibrating that band to std 2 multiplies the 16-bit weight
+rounding of the q/k/v/out projections by up to 3.5; its measured figures are pinned below, they are not north_star's.
+"""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vtc_oracle as O
+from oracle.parity_metrics import compare
+from vtc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-2
+AGREEMENT = 0.999
+RAW_BOUNDARY = 0.99       # segments of vtc_raw with both boundaries within one frame (both directions)
+MERGED_BOUNDARY = 0.95    # the same on vtc_merged (far fewer, much longer segments: one flip moves ~1 % of them)
+SECONDS = 600.0
+
+
+def _case(family, seed, chunk, calibrated=True):
+    from vtc_amd.engine import VtcEngine
+    w = O.make_weights(seed=seed, family=family, calibrated=calibrated)
+    audio = synth.synth_audio(SECONDS, seed=4000 + 10 * seed + int(chunk))
+    ref = O.apply_model_on_waveform(w, audio, chunk, batch_size=8)
+    eng = VtcEngine(w, n_labels=4, chunk_duration_s=chunk, max_batch=16, mfma_dtype="f16", device=0)
+    got = eng.infer_waveform(torch.from_numpy(audio).cuda(), batch_size=16)
+    torch.cuda.synchronize()
+    eng.close()
+    assert got.shape == ref.shape == (O.n_frames_for_samples(len(audio)), 4)
+    c = compare(ref, got.cpu())
+    print(json.dumps({"family": family, "seed": seed, "chunk": chunk, **c}))
+    return c
+
+
+@pytest.mark.parametrize("chunk", [4.0, 10.0])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_c1_600s_north_star_tolerances(seed, chunk):
+    c = _case("hubert", seed, chunk)
+    assert 1.6 <= c["logit_std"] <= 2.4, c["logit_std"]                  # calibrated on another clip: std ~ 2 here too
+    assert c["max_abs_logit_err"] <= LOGIT_TOL, c["max_abs_logit_err"]
+    assert c["frame_label_agreement"] >= AGREEMENT, c["frame_label_agreement"]
+    for table, bar in (("raw", RAW_BOUNDARY), ("merged", MERGED_BOUNDARY)):
+        assert c[table]["n_oracle"] > 50, "the recording must produce enough segments for the criterion to mean something"
+        assert min(c[table]["oracle_matched"], c[table]["gpu_matched"]) >= bar, (table, c[table])
+
+
+@pytest.mark.parametrize("seed,chunk", [(0, 10.0), (2, 10.0), (2, 4.0)])
+def test_c1_600s_adversarial_weight_family_is_pinned(seed, chunk):
+    """The three worst cases of the "stress" family (profiles/r02_parity_report.json has all eight)."""
+    c = _case("stress", seed, chunk)
+    assert c["max_abs_logit_err"] <= 3e-2, c["max_abs_logit_err"]
+    assert c["frame_label_agreement"] >= 0.998, c["frame_label_agreement"]
+    u = _case("stress", seed, chunk, calibrated=False)       # uncalibrated head (round 1's weights): inside the logit bar
+    assert u["max_abs_logit_err"] <= LOGIT_TOL, u["max_abs_logit_err"]

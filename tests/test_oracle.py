@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import vtc_oracle as O
+from vtc_amd import synth
 
 
 @pytest.fixture(scope="module")
@@ -134,3 +135,15 @@ def test_sigmoid_summary():
     mx, mean = O.sigmoid_summary(lg)
     assert mx == round(float(torch.sigmoid(torch.tensor(2.0))), 4)
     assert mean == 0.5
+
+
+def test_head_calibration_fixture_matches_the_generator(golden_dir):
+    doc = json.loads((golden_dir / "head_calibration.json").read_text())
+    assert doc["target_logit_std"] == 2.0
+    for key, e in doc["entries"].items():
+        assert synth.HEAD_CALIBRATION[key] == e["uncalibrated_logit_std"]
+        fam, seed = key.split(":")
+        a = synth.make_weights(seed=int(seed), family=fam)
+        b = synth.make_weights(seed=int(seed), family=fam, calibrated=True)
+        scale = np.float32(2.0 / e["uncalibrated_logit_std"])
+        assert np.array_equal(b["head.weight"], a["head.weight"] * scale) and np.array_equal(b["head.bias"], a["head.bias"] * scale)

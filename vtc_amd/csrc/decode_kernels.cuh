@@ -37,6 +37,17 @@ __device__ __forceinline__ bool next_active(const DecodeParams& p, long long f, 
   return frame_active(p, f + 1, l);
 }
 
+// Maximum that remembers a non-finite input: the sigmoid summary's max logit is NaN iff some logit of the rows it covers
+// is NaN or +-inf (an activation that left the 16-bit range upstream ends as NaN logits; a NaN compares false against every
+// bound, so without this mark such a recording would decode as "no speech" and look valid).
+__device__ __forceinline__ float max_keep_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+__device__ __forceinline__ float finite_or_nan(float x) { return fabsf(x) <= 3.4028234e38f ? x : __builtin_nanf(""); }
+__device__ __forceinline__ float wave_max_keep_nan(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max_keep_nan(v, __shfl_xor(v, o));
+  return v;
+}
+
 // counts: [2][nl][nblk] (0 = starts, 1 = ends); sig_sum[nblk] (fp64), max_logit[nblk]
 __global__ __launch_bounds__(256) void decode_count_kernel(DecodeParams p, int* __restrict__ counts,
                                                            double* __restrict__ sig_sum, float* __restrict__ max_logit) {
@@ -55,19 +66,19 @@ __global__ __launch_bounds__(256) void decode_count_kernel(DecodeParams p, int* 
     }
     if (f < p.n) {
       const float x = p.logits[f * p.nl + l];
-      ssum += (double)(1.f / (1.f + __expf(-x)));
-      mx = fmaxf(mx, x);
+      ssum += (double)(1.f / (1.f + expf(-x)));
+      mx = max_keep_nan(mx, finite_or_nan(x));
     }
   }
   __shared__ double rs[4];
   __shared__ float rm[4];
   ssum = wave_sum_d(ssum);
-  mx = wave_max(mx);
+  mx = wave_max_keep_nan(mx);
   if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = ssum; rm[threadIdx.x >> 6] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
     sig_sum[blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
-    max_logit[blockIdx.x] = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+    max_logit[blockIdx.x] = max_keep_nan(max_keep_nan(rm[0], rm[1]), max_keep_nan(rm[2], rm[3]));
   }
 }
 
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(1024) void decode_scan_kernel(int* __restrict__ cou
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double s = 0.0;
     float mx = -INFINITY;
-    for (int i = 0; i < nblk; ++i) { s += sig_sum[i]; mx = fmaxf(mx, max_logit[i]); }
+    for (int i = 0; i < nblk; ++i) { s += sig_sum[i]; mx = max_keep_nan(mx, max_logit[i]); }
     summary[0] = s;
     summary[1] = (double)mx;
   }
@@ -156,19 +167,28 @@ __global__ __launch_bounds__(256) void file_summary_kernel(const float* __restri
   float mx = -INFINITY;
   for (long long i = e0 + threadIdx.x; i < e1; i += 256) {
     const float x = logits[i];
-    ssum += (double)(1.f / (1.f + __expf(-x)));
-    mx = fmaxf(mx, x);
+    ssum += (double)(1.f / (1.f + expf(-x)));
+    mx = max_keep_nan(mx, finite_or_nan(x));
   }
   __shared__ double rs[4];
   __shared__ float rm[4];
   ssum = wave_sum_d(ssum);
-  mx = wave_max(mx);
+  mx = wave_max_keep_nan(mx);
   if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = ssum; rm[threadIdx.x >> 6] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
     out[2 * f] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
-    out[2 * f + 1] = (double)fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+    out[2 * f + 1] = (double)max_keep_nan(max_keep_nan(rm[0], rm[1]), max_keep_nan(rm[2], rm[3]));
   }
+}
+
+// apply_thresholds alone (the drop-in surface hands the 0/1 mask to the caller): mask[f][l] = lo[l] <= logit <= hi[l].
+__global__ __launch_bounds__(256) void threshold_mask_kernel(DecodeParams p, unsigned char* __restrict__ mask) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n * p.nl) return;
+  const int l = (int)(i % p.nl);
+  const float x = p.logits[i];
+  mask[i] = (x >= p.lo[l] && x <= p.hi[l]) ? 1 : 0;
 }
 
 // First frame of every recording of a multi-recording row layout (rows[f] = first row of recording f).

@@ -79,7 +79,7 @@ struct vtc_model {
   int slot = 0;
 
   // decode scratch (grown on demand)
-  long long dec_frames_cap = 0;
+  long long dec_frames_cap = 0, dec_run_cap = 0;   // frames the scratch holds; runs per label it holds
   int *dec_counts = nullptr, *dec_totals = nullptr, *dec_start = nullptr, *dec_end = nullptr;
   unsigned char* dec_fstart = nullptr;
   long long* fsum_rows = nullptr;   // vtc_decode_files per-recording summary scratch
@@ -373,24 +373,34 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   return 0;
 }
 
-int ensure_decode_scratch(vtc_model* m, long long n) {
-  if (n <= m->dec_frames_cap) return 0;
+// n frames in n_files recordings: runs never cross a recording, so a label has at most sum ceil(n_f / 2) <=
+// (n + n_files) / 2 runs (many 1-frame recordings, all active, reach it).
+long long max_runs_per_label(long long n, long long n_files) { return (n + n_files) / 2 + 1; }
+
+int ensure_decode_scratch(vtc_model* m, long long n, long long n_files) {
+  const long long runs = max_runs_per_label(n, n_files);
+  if (n <= m->dec_frames_cap && runs <= m->dec_run_cap) return 0;
   for (void* p : {(void*)m->dec_counts, (void*)m->dec_totals, (void*)m->dec_start, (void*)m->dec_end, (void*)m->dec_sig,
                   (void*)m->dec_summary, (void*)m->dec_max, (void*)m->dec_fstart})
     if (p) (void)hipFree(p);
+  m->dec_counts = m->dec_totals = m->dec_start = m->dec_end = nullptr;
+  m->dec_sig = m->dec_summary = nullptr; m->dec_max = nullptr; m->dec_fstart = nullptr;
+  const long long cap = std::max(n + n / 4 + 1024, m->dec_frames_cap);     // neither capacity ever shrinks
+  const long long rcap = std::max(runs + runs / 4 + 64, m->dec_run_cap);
   m->dec_frames_cap = 0;
-  const long long cap = n + n / 4 + 1024;
+  m->dec_run_cap = 0;
   const long long nblk = (cap + 255) / 256;
   const int nl = m->spec.n_labels;
   HIP_TRY(m, hipMalloc((void**)&m->dec_counts, sizeof(int) * 2 * nl * nblk));
   HIP_TRY(m, hipMalloc((void**)&m->dec_totals, sizeof(int) * 2 * VTC_MAX_LABELS));
-  HIP_TRY(m, hipMalloc((void**)&m->dec_start, sizeof(int) * nl * (cap / 2 + 1)));
-  HIP_TRY(m, hipMalloc((void**)&m->dec_end, sizeof(int) * nl * (cap / 2 + 1)));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_start, sizeof(int) * nl * rcap));
+  HIP_TRY(m, hipMalloc((void**)&m->dec_end, sizeof(int) * nl * rcap));
   HIP_TRY(m, hipMalloc((void**)&m->dec_sig, sizeof(double) * nblk));
   HIP_TRY(m, hipMalloc((void**)&m->dec_summary, sizeof(double) * 2));
   HIP_TRY(m, hipMalloc((void**)&m->dec_max, sizeof(float) * nblk));
   HIP_TRY(m, hipMalloc((void**)&m->dec_fstart, (size_t)cap + 1));
   m->dec_frames_cap = cap;
+  m->dec_run_cap = rcap;
   return 0;
 }
 
@@ -613,7 +623,7 @@ static int decode_impl(vtc_model* m, const float* logits, int64_t n, const float
   p.logits = logits; p.n = n; p.nl = nl; p.nblk = (int)((n + 255) / 256);
   p.file_start = file_start_dev;
   for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
-  const long long dcap = m->dec_frames_cap / 2 + 1;
+  const long long dcap = m->dec_run_cap;
   LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 4 * 2, s, {
     hipLaunchKernelGGL(decode_count_kernel, dim3(p.nblk), dim3(256), 0, s, p, m->dec_counts, m->dec_sig, m->dec_max);
     hipLaunchKernelGGL(decode_scan_kernel, dim3(2 * nl), dim3(1024), 0, s, m->dec_counts, p.nblk, m->dec_totals, m->dec_sig,
@@ -629,6 +639,8 @@ static int decode_impl(vtc_model* m, const float* logits, int64_t n, const float
   if (mean_sigmoid) *mean_sigmoid = summary[0] / ((double)n * nl);
   for (int l = 0; l < nl; ++l) {
     if (totals[l] != totals[nl + l]) return fail(m, VTC_ERR_HIP, "decode: label %d has %d starts but %d ends", l, totals[l], totals[nl + l]);
+    if (totals[l] < 0 || totals[l] > dcap)   // the emit kernel dropped runs: never hand out what lies past the label's region
+      return fail(m, VTC_ERR_HIP, "decode: label %d has %d runs, scratch holds %lld", l, totals[l], dcap);
     const int c = totals[l];
     runs_start[l].resize(c); runs_end[l].resize(c);
     if (!c) continue;
@@ -649,10 +661,13 @@ int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, co
     return fail(m, VTC_ERR_ARG, "null argument");
   if (n < 1 || n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
   HIP_TRY(m, hipSetDevice(m->device));
-  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  if (int rc = ensure_decode_scratch(m, n, 1)) return rc;
   const int nl = m->spec.n_labels;
   std::vector<int> rs[VTC_MAX_LABELS], re[VTC_MAX_LABELS];
-  if (int rc = decode_impl(m, logits, n, lo, hi, nullptr, rs, re, max_logit, mean_sigmoid, (hipStream_t)stream)) return rc;
+  float mx_all = 0.f;
+  if (int rc = decode_impl(m, logits, n, lo, hi, nullptr, rs, re, &mx_all, mean_sigmoid, (hipStream_t)stream)) return rc;
+  if (max_logit) *max_logit = mx_all;
+  if (mx_all != mx_all) return fail(m, VTC_ERR_NONFINITE, "non-finite logits (an activation left the 16-bit range)");
   long long total = 0;
   for (int l = 0; l < nl; ++l) total += (long long)rs[l].size();
   *n_out = total;
@@ -664,6 +679,25 @@ int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, co
       out_end[at] = (int64_t)re[l][k] * kRfStep + kRfSize;
       out_label[at] = l;
     }
+  return VTC_OK;
+}
+
+int vtc_threshold_mask(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi, uint8_t* mask,
+                       void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !lo || !hi || !mask) return fail(m, VTC_ERR_ARG, "null argument");
+  if (n < 0 || n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  if (n == 0) return VTC_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int nl = m->spec.n_labels;
+  DecodeParams p{};
+  p.logits = logits; p.n = n; p.nl = nl; p.nblk = 0;
+  for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
+  const long long blocks = (n * nl + 255) / 256;
+  LAUNCH(m, PC_DECODE, 0.0, (double)n * nl * 5, s,
+         hipLaunchKernelGGL(threshold_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, mask));
+  HIP_TRY(m, hipGetLastError());
   return VTC_OK;
 }
 
@@ -716,7 +750,7 @@ int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows
   if (n > 0x7fffff00LL) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
   HIP_TRY(m, hipSetDevice(m->device));
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  if (int rc = ensure_decode_scratch(m, n, n_files)) return rc;
   std::vector<unsigned char> mask((size_t)n + 1, 0);
   for (int f = 0; f < n_files; ++f) if (file_rows[f] < n) mask[(size_t)file_rows[f]] = 1;
   HIP_TRY(m, hipMemcpyAsync(m->dec_fstart, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
@@ -736,7 +770,10 @@ int vtc_decode_files(vtc_model* m, const float* logits, const int64_t* file_rows
            hipLaunchKernelGGL(file_summary_kernel, dim3(n_files), dim3(256), 0, s, logits, nl, m->fsum_rows, m->fsum_out));
   }
   std::vector<int> rs[VTC_MAX_LABELS], re[VTC_MAX_LABELS];
-  if (int rc = decode_impl(m, logits, n, lo, hi, m->dec_fstart, rs, re, nullptr, nullptr, s)) return rc;   // synchronises s
+  float mx_all = 0.f;
+  if (int rc = decode_impl(m, logits, n, lo, hi, m->dec_fstart, rs, re, &mx_all, nullptr, s)) return rc;   // synchronises s
+  if (mx_all != mx_all && !max_logit)   // with max_logit the affected recordings are marked NaN below instead
+    return fail(m, VTC_ERR_NONFINITE, "non-finite logits (an activation left the 16-bit range)");
   if (max_logit || mean_sigmoid) {
     std::vector<double> hsum((size_t)2 * n_files);
     HIP_TRY(m, hipMemcpyAsync(hsum.data(), m->fsum_out, sizeof(double) * 2 * n_files, hipMemcpyDeviceToHost, s));
@@ -819,9 +856,9 @@ int vtc_decode_launch(vtc_model* m, const float* logits, const int64_t* file_row
     m->dec_active = true;
     return VTC_OK;
   }
-  if (int rc = ensure_decode_scratch(m, n)) return rc;
+  if (int rc = ensure_decode_scratch(m, n, n_files)) return rc;
   if (int rc = ensure_file_scratch(m, n_files)) return rc;
-  const long long rcap = n / 2 + 1, dcap = m->dec_frames_cap / 2 + 1;
+  const long long rcap = max_runs_per_label(n, n_files), dcap = m->dec_run_cap;
   const size_t off_fsum = kDecHostHead, off_rows = off_fsum + sizeof(double) * 2 * (size_t)n_files;
   const size_t off_rs = (off_rows + sizeof(int64_t) * ((size_t)n_files + 1) + 63) & ~(size_t)63;
   const size_t off_re = off_rs + sizeof(int) * (size_t)nl * rcap, need = off_re + sizeof(int) * (size_t)nl * rcap;
@@ -860,7 +897,7 @@ int vtc_decode_launch(vtc_model* m, const float* logits, const int64_t* file_row
   });
   HIP_TRY(m, hipMemcpyAsync(h, m->dec_totals, sizeof(int) * 2 * nl, hipMemcpyDeviceToHost, s));
   HIP_TRY(m, hipMemcpyAsync(h + 128, m->dec_summary, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-  // the run lists at their full capacity (n/2 + 1 per label): their lengths are only known on the device, and a
+  // the run lists at their full capacity ((n + n_files)/2 + 1 per label): their lengths are only known on the device, and a
   // second, length-sized copy would have to queue behind whatever the caller enqueues next
   HIP_TRY(m, hipMemcpy2DAsync(h + off_rs, sizeof(int) * rcap, m->dec_start, sizeof(int) * dcap, sizeof(int) * rcap, nl,
                               hipMemcpyDeviceToHost, s));
@@ -910,6 +947,10 @@ int vtc_decode_collect(vtc_model* m, int32_t* out_file, int64_t* out_start, int6
     total += totals[l];
   }
   *n_out = total;
+  if (summary[1] != summary[1] && !(m->dec_want_summary && max_logit)) {   // otherwise max_logit[f] = NaN marks the recordings
+    m->dec_active = false;
+    return fail(m, VTC_ERR_NONFINITE, "non-finite logits (an activation left the 16-bit range)");
+  }
   if (total > cap)   // the results stay parked: call again with room for *n_out runs
     return fail(m, VTC_ERR_CAPACITY, "decode: %lld intervals, caller capacity %lld", total, (long long)cap);
   if (m->dec_want_summary) {

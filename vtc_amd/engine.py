@@ -18,6 +18,22 @@ RF_STEP = 320   # reference: src/analysis/chunk_artifact.py:51
 RF_SIZE = 400   # reference: src/analysis/chunk_artifact.py:11-13
 DTYPES = {"bf16": 0, "f16": 1}
 
+import weakref
+
+_LIVE: "weakref.WeakSet[VtcEngine]" = weakref.WeakSet()   # engines with an open handle (segma_compat resolves foreign tensors)
+_SERIAL = [0]
+
+
+def live_engines(n_labels: int | None = None, device=None) -> list:
+    """Open engines, newest first, optionally only those with this label count / on this device."""
+    out = [e for e in _LIVE if getattr(e, "_handle", None) and e._handle.value]
+    if n_labels is not None:
+        out = [e for e in out if e.n_labels == int(n_labels)]
+    if device is not None and torch.device(device).type == "cuda":
+        d = torch.device(device)
+        out = [e for e in out if d.index is None or e.device.index == d.index]
+    return sorted(out, key=lambda e: -e._serial)
+
 
 def frames_for_samples(n_samples: int) -> int:
     return 0 if n_samples < RF_SIZE else (n_samples - RF_SIZE) // RF_STEP + 1
@@ -95,12 +111,16 @@ class VtcEngine:
         L.check(self._lib.vtc_create(C.byref(spec), C.byref(w), dev_index, C.byref(self._handle)), None)
         self.frames_per_window = int(self._lib.vtc_frames_per_window(self._handle))
         self.step = self.frames_per_window * RF_STEP   # reference: chunk_artifact.py:71-73
+        _SERIAL[0] += 1
+        self._serial = _SERIAL[0]
+        _LIVE.add(self)
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         if getattr(self, "_handle", None) and self._handle.value:
             self._lib.vtc_destroy(self._handle)
             self._handle = C.c_void_p()
+            _LIVE.discard(self)
 
     def __del__(self):
         try:
@@ -276,6 +296,20 @@ class VtcEngine:
         return out[: got.value]
 
     # ------------------------------------------------------------------ decode
+    def threshold_mask(self, logits: torch.Tensor, lo_logit, hi_logit) -> torch.Tensor:
+        """(n_frames, n_labels) uint8 0/1 mask on the device (include/vtc_amd.h: vtc_threshold_mask)."""
+        if logits.device != self.device or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError("logits must be a contiguous float32 tensor on the engine's device")
+        lo = np.ascontiguousarray(lo_logit, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_logit, dtype=np.float32)
+        if len(lo) != self.n_labels or len(hi) != self.n_labels or logits.dim() != 2 or logits.shape[1] != self.n_labels:
+            raise ValueError("need (n_frames, n_labels) logits and one lower and one upper bound per label")
+        mask = torch.empty(logits.shape, dtype=torch.uint8, device=self.device)
+        L.check(self._lib.vtc_threshold_mask(self._handle, C.c_void_p(logits.data_ptr()), int(logits.shape[0]),
+                                             lo.ctypes.data_as(L._f32p), hi.ctypes.data_as(L._f32p),
+                                             C.c_void_p(mask.data_ptr()), self._stream()), self._handle)
+        return mask
+
     def decode(self, logits: torch.Tensor, lo_logit, hi_logit):
         """Threshold + run-length decode on the GPU (include/vtc_amd.h: vtc_decode).
 

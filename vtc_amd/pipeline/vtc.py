@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import logging
+import math
 import os
 import sys
 import threading
@@ -193,6 +194,10 @@ def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | Non
     dict per segment: a block is (uid, onset, offset, duration, label_codes) with numpy arrays, joined into the shard's
     table by utils.segments_table_from_blocks; same values as core.intervals.intervals_to_segments / vtc_meta_row."""
     starts, ends, lab, max_logit, mean_sig, _, cpu_logits = decoded
+    if not math.isfinite(max_logit) and not max_logit == -math.inf:
+        # vtc_decode_collect marks a recording with NaN / inf logits by max_logit = NaN (include/vtc_amd.h): fp16 storage
+        # overflowed somewhere upstream; such a file gets an error row, never an empty-looking valid one
+        raise ValueError("non-finite logits: an activation left the range of the 16-bit storage type (try engine.mfma_dtype: bf16)")
     if save_to is not None:
         torch.save({labels[j]: cpu_logits[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
     onset, offset, duration, keep = intervals_to_columns(starts, ends)
