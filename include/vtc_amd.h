@@ -117,6 +117,25 @@ int vtc_decode(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, co
 int vtc_threshold_mask(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,
                        const float* hi_logit /*[host]*/, uint8_t* mask /*[dev] n_frames x n_labels*/, void* stream);
 
+/* vtc_decode for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference (its decode is a Python loop on the host, vtc.py:84-91); same arithmetic and
+ * the same kernels as vtc_decode, but
+ *   - the scratch the kernels need (per-block run counts, their scan, the per-label run lists, the sigmoid partials)
+ *     lives in a file-scope device array of the library, VTC_STATIC_DECODE_BYTES per GPU, held until the process ends;
+ *   - every output is DEVICE memory of the caller, so nothing is copied to the host and nothing synchronises: the call only
+ *     enqueues four kernels on `stream` and performs no hipMalloc / hipFree / host allocation.
+ * Limits: n_frames <= VTC_STATIC_DECODE_MAX_FRAMES (larger inputs are rejected with VTC_ERR_CAPACITY; use vtc_decode).
+ * result[0] receives the number of intervals found (if it exceeds `cap` only the first `cap` were written; -1 if the run
+ * lists were inconsistent), result_summary = {max logit (NaN if a logit is non-finite, as vtc_decode_files), mean sigmoid}.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two models) race;
+ * nothing has to be cleared between calls (every word a call reads it has written itself). */
+#define VTC_STATIC_DECODE_MAX_FRAMES 262144   /* 87 min of audio at 20 ms per frame */
+#define VTC_STATIC_DECODE_BYTES ((8u << 20) + (1u << 17))
+int vtc_decode_static(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,
+                      const float* hi_logit /*[host]*/, int64_t* out_start /*[dev]*/, int64_t* out_end /*[dev]*/,
+                      int32_t* out_label /*[dev]*/, int64_t cap, int64_t* result /*[dev] 1*/,
+                      double* result_summary /*[dev] 2*/, void* stream);
+
 /* Several recordings in one call (second caller of the boundary: src/analysis/vtc_on_clips.py:154-211 runs
  * apply_model_on_audio once per packaged clip, most of them shorter than a batch of windows).  Recording f is
  * wav[offset[f] .. offset[f] + n_samples[f]) of one device arena; windows are planned per recording exactly as in

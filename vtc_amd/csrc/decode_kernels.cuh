@@ -191,6 +191,39 @@ __global__ __launch_bounds__(256) void threshold_mask_kernel(DecodeParams p, uns
   mask[i] = (x >= p.lo[l] && x <= p.hi[l]) ? 1 : 0;
 }
 
+// Last pass of the no-allocation decode (vtc_decode_static): per-label run lists (frame indices) -> the caller's device
+// arrays in vtc_decode's order (label-major, time-ordered) and units (samples).  result[0] = number of runs (all of them,
+// also when only `cap` fit), or -1 if a label's starts and ends disagree; summary_out = {max logit, mean sigmoid}.
+__global__ __launch_bounds__(256) void decode_pack_kernel(const int* __restrict__ totals, const int* __restrict__ run_start,
+                                                          const int* __restrict__ run_end, long long run_cap, int nl,
+                                                          long long cap, long long* __restrict__ out_start,
+                                                          long long* __restrict__ out_end, int* __restrict__ out_label,
+                                                          long long* __restrict__ result, const double* __restrict__ summary,
+                                                          double n_values, double* __restrict__ summary_out) {
+  long long base = 0, total = 0;
+  bool ok = true;
+  const int l = blockIdx.y;
+  for (int j = 0; j < nl; ++j) {
+    const int c = totals[j];
+    ok = ok && c == totals[nl + j] && c >= 0 && c <= run_cap;
+    if (j < l) base += c;
+    total += c;
+  }
+  if (blockIdx.x == 0 && l == 0 && threadIdx.x == 0) {
+    result[0] = ok ? total : -1;
+    summary_out[0] = summary[1];
+    summary_out[1] = summary[0] / n_values;
+  }
+  if (!ok) return;
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= totals[l]) return;
+  const long long at = base + k;
+  if (at >= cap) return;
+  out_start[at] = (long long)run_start[l * run_cap + k] * kRfStep;
+  out_end[at] = (long long)run_end[l * run_cap + k] * kRfStep + kRfSize;
+  out_label[at] = l;
+}
+
 // First frame of every recording of a multi-recording row layout (rows[f] = first row of recording f).
 __global__ void mark_file_starts_kernel(const long long* __restrict__ rows, int n_files, long long n, unsigned char* __restrict__ mask) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;

@@ -37,6 +37,26 @@ const char* kProfNames[VTC_PROF_CLASSES] = {"conv0_stats", "conv0_apply", "gemm_
 
 thread_local std::string g_create_error;
 
+// ---- scratch of the no-allocation decode (include/vtc_amd.h: vtc_decode_static).  One copy per GPU, at its own address:
+// the name below is a host-side stand-in, never a device pointer; vtc_create resolves the address on its device with
+// hipGetSymbolAddress and everything else uses that pointer.
+constexpr long long kStMaxFrames = VTC_STATIC_DECODE_MAX_FRAMES;
+constexpr long long kStNblk = kStMaxFrames / 256;
+constexpr long long kStRunCap = kStMaxFrames / 2 + 1;
+constexpr size_t kStOffCounts = 0;                                                        // int [2][8][nblk]
+constexpr size_t kStOffTotals = kStOffCounts + sizeof(int) * 2 * VTC_MAX_LABELS * kStNblk;  // int [16]
+constexpr size_t kStOffSummary = kStOffTotals + 256;                                      // double [2]
+constexpr size_t kStOffSig = kStOffSummary + 256;                                         // double [nblk]
+constexpr size_t kStOffMax = kStOffSig + sizeof(double) * kStNblk;                        // float [nblk]
+constexpr size_t kStOffStart = (kStOffMax + sizeof(float) * kStNblk + 255) & ~(size_t)255;  // int [8][run cap]
+constexpr size_t kStOffEnd = (kStOffStart + sizeof(int) * VTC_MAX_LABELS * kStRunCap + 255) & ~(size_t)255;
+constexpr size_t kStBytes = kStOffEnd + sizeof(int) * VTC_MAX_LABELS * kStRunCap;
+static_assert(kStBytes <= VTC_STATIC_DECODE_BYTES, "scratch layout exceeds the size the header states");
+static __device__ __align__(256) unsigned char scratch[VTC_STATIC_DECODE_BYTES];
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU
+std::mutex g_scratch_mu;
+
 struct LayerDev {
   h16 *qkv_w, *o_w, *ff1_w, *ff2_w;
   float *qkv_b, *o_b, *ff1_b, *ff2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
@@ -468,6 +488,15 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   }
   if (m->L[6] != m->T) return bail(fail(m, VTC_ERR_ARG, "geometry mismatch"));
   if (hipSetDevice(device) != hipSuccess) return bail(fail(m, VTC_ERR_HIP, "hipSetDevice(%d) failed", device));
+  if (device < kMaxDevices) {   // once per device, with that device current: where this GPU keeps its copy of `scratch`
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+      void* ptr = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !ptr) return bail(fail(m, VTC_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)));
+      g_scratch_ptr[device] = (unsigned char*)ptr;
+    }
+  }
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
   const bool f16 = m->f16;
@@ -679,6 +708,42 @@ int vtc_decode(vtc_model* m, const float* logits, int64_t n, const float* lo, co
       out_end[at] = (int64_t)re[l][k] * kRfStep + kRfSize;
       out_label[at] = l;
     }
+  return VTC_OK;
+}
+
+int vtc_decode_static(vtc_model* m, const float* logits, int64_t n, const float* lo, const float* hi, int64_t* out_start,
+                      int64_t* out_end, int32_t* out_label, int64_t cap, int64_t* result, double* result_summary, void* stream) {
+  if (!m) return VTC_ERR_ARG;
+  if (!logits || !lo || !hi || !result || !result_summary || cap < 0 || (cap > 0 && (!out_start || !out_end || !out_label)))
+    return fail(m, VTC_ERR_ARG, "null argument");
+  if (n < 1) return fail(m, VTC_ERR_ARG, "n_frames %lld out of range", (long long)n);
+  if (n > kStMaxFrames)
+    return fail(m, VTC_ERR_CAPACITY, "vtc_decode_static holds %lld frames at most, got %lld (use vtc_decode)", kStMaxFrames,
+                (long long)n);
+  unsigned char* base = m->device < kMaxDevices ? g_scratch_ptr[m->device] : nullptr;
+  if (!base) return fail(m, VTC_ERR_HIP, "static scratch of device %d was not resolved", m->device);
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int nl = m->spec.n_labels;
+  int* counts = (int*)(base + kStOffCounts);
+  int* totals = (int*)(base + kStOffTotals);
+  double* summary = (double*)(base + kStOffSummary);
+  double* sig = (double*)(base + kStOffSig);
+  float* mx = (float*)(base + kStOffMax);
+  int* run_start = (int*)(base + kStOffStart);
+  int* run_end = (int*)(base + kStOffEnd);
+  DecodeParams p{};
+  p.logits = logits; p.n = n; p.nl = nl; p.nblk = (int)((n + 255) / 256);
+  p.file_start = nullptr;
+  for (int l = 0; l < nl; ++l) { p.lo[l] = lo[l]; p.hi[l] = hi[l]; }
+  const long long rcap = n / 2 + 1;   // <= kStRunCap; the label regions are laid out with this stride
+  hipLaunchKernelGGL(decode_count_kernel, dim3(p.nblk), dim3(256), 0, s, p, counts, sig, mx);
+  hipLaunchKernelGGL(decode_scan_kernel, dim3(2 * nl), dim3(1024), 0, s, counts, p.nblk, totals, sig, mx, summary);
+  hipLaunchKernelGGL(decode_emit_kernel, dim3(p.nblk), dim3(256), 0, s, p, counts, rcap, run_start, run_end);
+  hipLaunchKernelGGL(decode_pack_kernel, dim3((unsigned)((rcap + 255) / 256), nl), dim3(256), 0, s, totals, run_start, run_end, rcap,
+                     nl, (long long)cap, (long long*)out_start, (long long*)out_end, out_label, (long long*)result, summary,
+                     (double)n * nl, result_summary);
+  HIP_TRY(m, hipGetLastError());
   return VTC_OK;
 }
 

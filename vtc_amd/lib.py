@@ -14,6 +14,7 @@ ABI_VERSION = 1
 MAX_LABELS = 8
 N_LAYERS = 12
 PROF_CLASSES = 8
+STATIC_DECODE_MAX_FRAMES = 262144
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_GPU, ERR_CAPACITY, ERR_SHORT, ERR_NONFINITE = 0, -1, -2, -3, -4, -5, -6
 
@@ -65,6 +66,8 @@ SYMBOLS = {
     "vtc_infer_waveform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, _i64p, C.c_void_p]),
     "vtc_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _f32p, _f32p, _i64p, _i64p, _i32p, C.c_int64, _i64p,
                              _f32p, _f64p, C.c_void_p]),
+    "vtc_decode_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "vtc_threshold_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _f32p, _f32p, C.c_void_p, C.c_void_p]),
     "vtc_infer_waveforms": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i64p, C.c_int32, C.c_int32, C.c_void_p, _i64p, C.c_void_p]),
     "vtc_decode_files": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, C.c_int32, _f32p, _f32p, _i32p, _i64p, _i64p, _i32p, C.c_int64,
