@@ -507,11 +507,12 @@ def test_launcher_builds_one_worker_per_device(monkeypatch):
     """vtc_amd.launcher: options before "--" are the launcher's, everything after goes to every worker; worker i sees one
     device and gets --array_id i --array_count N (the reference's SLURM array, slurm/vtc.slurm:10)."""
     from vtc_amd import launcher
-    calls = []
+    calls, envs = [], []
 
     class FakeProc:
         def __init__(self, cmd, env):
             calls.append((cmd, env["HIP_VISIBLE_DEVICES"], env["HSA_ENABLE_IPC_MODE_LEGACY"]))
+            envs.append(env)
 
         def wait(self):
             return 0 if len(calls) != 99 else 1
@@ -519,10 +520,14 @@ def test_launcher_builds_one_worker_per_device(monkeypatch):
     monkeypatch.setattr(launcher.subprocess, "Popen", lambda cmd, env: FakeProc(cmd, env))
     assert launcher.main(["chunks30", "--gpus", "3", "--", "--checkpoint", "best.ckpt", "--balance"]) == 0
     assert [c[1] for c in calls] == ["0", "1", "2"] and all(c[2] == "0" for c in calls)
+    slices = launcher.worker_cpu_slices(3)
     for i, (cmd, _, _) in enumerate(calls):
+        readers = str(launcher.thread_budget(len(slices[i]))["readers"])
         assert cmd[1:] == ["-m", "vtc_amd.pipeline.vtc", "chunks30", "--array_id", str(i), "--array_count", "3",
-                           "--checkpoint", "best.ckpt", "--balance"]
-    calls.clear()
-    assert launcher.main(["ds", "--devices", "0,0", "--", "--batch_size", "8"]) == 0          # two workers on one GPU
-    assert [c[1] for c in calls] == ["0", "0"] and calls[1][0][-4:] == ["--array_count", "2", "--batch_size", "8"]
+                           "--prefetch", readers, "--checkpoint", "best.ckpt", "--balance"]
+        assert envs[i]["VTC_WORKER_CPUS"] == ",".join(str(c) for c in slices[i]) and envs[i]["OMP_NUM_THREADS"] == "1"
+    calls.clear(); envs.clear()
+    assert launcher.main(["ds", "--devices", "0,0", "--no_affinity", "--", "--batch_size", "8", "--prefetch", "3"]) == 0   # two workers on one GPU
+    assert [c[1] for c in calls] == ["0", "0"] and calls[1][0][-6:] == ["--array_count", "2", "--batch_size", "8", "--prefetch", "3"]
+    assert "VTC_WORKER_CPUS" not in envs[0] or envs[0].get("VTC_WORKER_CPUS") == os.environ.get("VTC_WORKER_CPUS")
     assert launcher.main(["ds", "--gpus", "3", "--devices", "0,1"]) == 2                       # count mismatch
