@@ -336,10 +336,12 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const h16* __restrict
 // in flight per wave (the kernel is a pure stream over rows that the producing GEMM left in L2 / Infinity Cache).
 constexpr int kLnRows = 2;
 
-template <bool F16, bool HEAD, bool IN16 = false>
-__global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restrict__ in, const float* __restrict__ g,
-                                                           const float* __restrict__ bt, float* __restrict__ out32,
-                                                           h16* __restrict__ out16, int rows, HeadParams hp) {
+// IN: 0 = fp32 rows, 1 = 16-bit rows.
+template <bool F16, bool HEAD, int IN = 0>
+__global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restrict__ in,
+                                                           const float* __restrict__ g, const float* __restrict__ bt,
+                                                           float* __restrict__ out32, h16* __restrict__ out16, int rows,
+                                                           HeadParams hp) {
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLnRows;
   if (row0 >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restric
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float4 x;
-      if constexpr (IN16) {
+      if constexpr (IN == 1) {
         const u16x4 h = *(const u16x4*)((const h16*)in + (long long)row * 768 + i * 256 + lane * 4);
         x = make_float4(from_h16<F16>(h[0]), from_h16<F16>(h[1]), from_h16<F16>(h[2]), from_h16<F16>(h[3]));
       } else {
@@ -382,8 +384,9 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restric
       v[r][4 * i + 2] = fmaf(v[r][4 * i + 2] * rstd, gg[i].z, bb[i].z);
       v[r][4 * i + 3] = fmaf(v[r][4 * i + 3] * rstd, gg[i].w, bb[i].w);
       if (out32) *(float4*)(out32 + (long long)row * 768 + c) = make_float4(v[r][4 * i], v[r][4 * i + 1], v[r][4 * i + 2], v[r][4 * i + 3]);
-      *(uint2*)(out16 + (long long)row * 768 + c) =
-          make_uint2(pack2<F16>(v[r][4 * i], v[r][4 * i + 1]), pack2<F16>(v[r][4 * i + 2], v[r][4 * i + 3]));
+      if (out16)
+        *(uint2*)(out16 + (long long)row * 768 + c) =
+            make_uint2(pack2<F16>(v[r][4 * i], v[r][4 * i + 1]), pack2<F16>(v[r][4 * i + 2], v[r][4 * i + 3]));
     }
     if constexpr (HEAD) {
       const int b = row / hp.T, t = row - b * hp.T;
@@ -402,6 +405,58 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restric
       }
     }
   }
+}
+
+// Entry of the LayerNorm-free transformer layers (gemm256.cuh): fp32 pre-LN rows (pos-conv output + residual) -> 16-bit
+// rows and the row statistics (mean, rstd) of the encoder's input LayerNorm; one wave per row, two-pass.
+template <bool F16>
+__global__ __launch_bounds__(256) void ln_round_stats_kernel(const float* __restrict__ in, h16* __restrict__ out_h,
+                                                             float* __restrict__ stats, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float v[12];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 x = *(const float4*)(in + (long long)row * 768 + i * 256 + lane * 4);
+    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+    s += (x.x + x.y) + (x.z + x.w);
+  }
+  const float mean = wave_sum(s) * (1.f / 768.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + 1e-5f);
+  if (lane == 0) *(float2*)(stats + (long long)row * 2) = make_float2(mean, rstd);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const long long at = (long long)row * 768 + i * 256 + lane * 4;
+    *(uint2*)(out_h + at) = make_uint2(pack2<F16>(v[4 * i], v[4 * i + 1]), pack2<F16>(v[4 * i + 2], v[4 * i + 3]));
+  }
+}
+
+// Row statistics from the 16 partials the EPI_LNRES epilogue left (each the mean and centred sum of squares of 48 columns):
+// equal group sizes, so mean = average of the group means and M2 = sum of the group M2 + 48 * sum (group mean - mean)^2
+// (Chan et al.), always in the same order: bit-reproducible.  One thread per row.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float mp[16], qp[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 t = *(const float4*)(part + (long long)row * 32 + i * 4);
+    mp[2 * i] = t.x; qp[2 * i] = t.y; mp[2 * i + 1] = t.z; qp[2 * i + 1] = t.w;
+  }
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sm += mp[i]; sq += qp[i]; }
+  const float mean = sm * (1.f / 16.f);
+  float dev = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const float d = mp[i] - mean; dev = fmaf(d, d, dev); }
+  const float var = fmaf(48.f, dev, sq) * (1.f / 768.f);
+  *(float2*)(stats + (long long)row * 2) = make_float2(mean, rsqrtf(var + 1e-5f));
 }
 
 // Positional-conv input: fp32 (B*T, 768) -> zero-padded group-major 16-bit (B, 16, T+128, 48) so the

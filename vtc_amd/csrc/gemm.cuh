@@ -15,7 +15,10 @@
 
 namespace vtc {
 
-enum : int { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_F32 = 8, EPI_RESID16 = 16 };  // RESID16: residual stored 16-bit
+enum : int { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_F32 = 8, EPI_RESID16 = 16,   // RESID16: residual stored 16-bit
+             // LayerNorm-free transformer layers (gemm256 only; see gemm256.cuh "LayerNorm without a LayerNorm kernel"):
+             EPI_LNIN = 32,    // A holds PRE-LayerNorm rows; the normalisation is applied to the accumulators
+             EPI_LNRES = 64 }; // residual = LayerNorm of 16-bit pre-LN rows; output = pre-LN rows + partial row statistics
 
 struct GemmParams {
   const h16* A;
@@ -33,6 +36,13 @@ struct GemmParams {
   int c_col_z;
   int tiles_m, tiles_n;
   int group_n;               // gemm256: tile columns per L2 group (divides tiles_n), see tile_coords()
+  // EPI_LNIN / EPI_LNRES (gemm256)
+  const float* ln_stats;     // [M][2] (mean, rstd) of the LayerNorm that feeds A (LNIN) or the residual (LNRES)
+  const float* colsum;       // LNIN: [N] sum over k of the 16-bit weights W[n][k] (gamma is folded into W, beta into bias)
+  const h16* res_h;          // LNRES: 16-bit pre-LN rows the residual is the LayerNorm of (may alias C: a lane reads exactly
+                             //        the elements it later writes)
+  const float* res_g;        // LNRES: [N] gamma of that LayerNorm (its beta is folded into bias)
+  float* part;               // LNRES: [M][16][2] (mean, M2) of the output row over 16 groups of 48 columns
 };
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }

@@ -23,6 +23,21 @@
 //     transpose and stores 16 B per lane straight from the accumulators.
 //   * persistent: a block walks tiles b, b+G, b+2G, ...; the NEXT tile's prologue loads are issued before
 //     the current tile's epilogue (registers only), so loads and stores overlap.
+//
+// LayerNorm without a LayerNorm kernel (post-LN transformer layers, modeling_hubert.py:387-397).  The residual stream is
+// kept as 16-bit PRE-LayerNorm rows u (what the next GEMM reads as its A operand) plus per-row statistics (mean, rstd):
+//   EPI_LNRES (out-proj, FFN2):  v = acc + bias' + gamma_c * ((u - mean_r) * rstd_r)   [bias' = bias + beta]
+//       writes v (16 bit) and, per row, the (mean, M2) of the fp32 v over each wave's 48 columns: 16 partials per row in a
+//       fixed layout, merged in a fixed order by ln_stats_finalize_kernel, so the result is bit-reproducible (no atomics).
+//   EPI_LNIN (QKV, FFN1):  LN(u) W^T + b = rstd_r * (u W'^T - mean_r * s_c) + b'  with W' = gamma o W rounded to 16 bit,
+//       s_c = sum_k W'[c][k] (of the rounded weights, so the mean cancels exactly), b' = b + W beta.
+// Rounding: the residual stream is rounded to 16 bit once per LayerNorm (u), where the LayerNorm-kernel form rounded
+// twice (the pre-LN rows and the LayerNorm output); statistics come from the fp32 values.  24 LayerNorm launches per
+// forward (4 B per element each) become 24 launches of a 5 us statistics merge.
+// Tried and dropped: carrying the low halves u_l = u - fp16(u) as a second 16-bit array (residual exact to ~22 bits: 37 %
+// less logit error instead of 17 %).  Twice the epilogue loads and stores need either a second pass of loads behind the
+// first pass's stores (a full vmcnt(0) drain that waits for the store acknowledgements of the chip-wide output burst:
+// +33..45 us per launch) or ~100 more live registers than the kernel has (96 spilled).
 #pragma once
 #include "common.cuh"
 #include "gemm.cuh"
@@ -72,6 +87,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   using TC = Tile256<BN>;
   constexpr int NJ1 = TC::NJ1;
   static_assert(!(EPI & EPI_RESID), "fp32 residual is not supported here (the encoder keeps a 16-bit residual stream)");
+  static_assert(!(EPI & EPI_LNRES) || (BN == 192 && !(EPI & (EPI_F32 | EPI_GELU | EPI_RESID16 | EPI_LNIN))),
+                "EPI_LNRES: 192-wide tiles (16 groups of 48 columns per 768-wide row), split 16-bit output");
   __shared__ __attribute__((aligned(16))) char smem[TC::SMEM];
 
   const int tid = threadIdx.x;
@@ -341,10 +358,114 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned rowoff[8];   // element offset of (row, column 0 of the z slice), or OOB
+    unsigned rowidx[8];   // the row itself, or OOB (offsets into the per-row statistics)
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int row = tile_m * 256 + (g >> 2) * 128 + wm * 64 + (g & 3) * 16 + fr;
       rowoff[g] = row < p.M ? (unsigned)(row * p.ldc) : OOB;
+      rowidx[g] = row < p.M ? (unsigned)row : OOB;
+    }
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rstat = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.ln_stats, 0, (EPI & (EPI_LNIN | EPI_LNRES)) ? (int)((long long)p.M * 8) : 0, 0x00020000);
+    if constexpr (EPI & EPI_LNRES) {
+      // ---- residual = LayerNorm(u_h + u_l), output rows split into two 16-bit halves, partial row statistics.
+      // Four passes of two row groups: the residual halves of a pass are all fetched before its first store.
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)p.res_h, 0, (int)((long long)p.M * p.ldc * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rpart = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, (int)((long long)p.M * 128), 0x00020000);
+      float gv0[8], gv1[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 t = *(const float4*)(p.res_g + col0 + 4 * q);
+        gv0[4 * q] = t.x; gv0[4 * q + 1] = t.y; gv0[4 * q + 2] = t.z; gv0[4 * q + 3] = t.w;
+      }
+      {
+        const float4 t = *(const float4*)(p.res_g + col1);
+        gv1[0] = t.x; gv1[1] = t.y; gv1[2] = t.z; gv1[3] = t.w;
+      }
+      const unsigned part_col = (unsigned)((tile_n * 4 + wn) * 8);   // byte offset of this wave's (mean, M2) inside a row's 128 B
+      // vmcnt counts loads and stores alike and the compiler has to assume they complete out of order, so any wait for a
+      // load while a store is pending is a full drain (vmcnt(0)): it then waits for the store acknowledgements of the whole
+      // chip's output burst, microseconds per tile (measured: a second pass of loads behind the first pass's stores costs
+      // 15 us per launch).  Hence every load of the tile is issued and waited for (the empty asm "uses" each register while
+      // only loads are pending, so the wait is a counted one) before the first store.
+      auto row_of = [&](int g) { return tile_m * 256 + (g >> 2) * 128 + wm * 64 + (g & 3) * 16 + fr; };
+      u32x4 h0[8];
+      u32x2 h1[8], st[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int row = row_of(g);
+        const unsigned ro = row < p.M ? (unsigned)(row * p.ldc) : OOB;
+        h0[g] = __builtin_amdgcn_raw_buffer_load_b128(rh, ro == OOB ? OOB : (ro + (unsigned)col0) * 2u, 0, 0);
+        h1[g] = __builtin_amdgcn_raw_buffer_load_b64(rh, ro == OOB ? OOB : (ro + (unsigned)col1) * 2u, 0, 0);
+        st[g] = __builtin_amdgcn_raw_buffer_load_b64(rstat, row < p.M ? (unsigned)row * 8u : OOB, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(h0[g]), "v"(h1[g]), "v"(st[g]));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int mq = g >> 2, i = g & 3;
+        const int row = row_of(g);
+        const unsigned ro = row < p.M ? (unsigned)(row * p.ldc) : OOB;
+        const float a_r = __uint_as_float(st[g][1]);                 // rstd
+        const float b_r = -__uint_as_float(st[g][0]) * a_r;          // -mean * rstd
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float ua = from_h16<F16>((h16)(h0[g][k] & 0xffffu)), ub = from_h16<F16>((h16)(h0[g][k] >> 16));
+          const int c = 2 * k;
+          v[c] = fmaf(gv0[c], fmaf(a_r, ua, b_r), acc0[mq][i][c >> 2][c & 3] + bv0[c]);
+          v[c + 1] = fmaf(gv0[c + 1], fmaf(a_r, ub, b_r), acc0[mq][i][(c + 1) >> 2][(c + 1) & 3] + bv0[c + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float ua = from_h16<F16>((h16)(h1[g][k] & 0xffffu)), ub = from_h16<F16>((h16)(h1[g][k] >> 16));
+          const int c = 2 * k;
+          v[8 + c] = fmaf(gv1[c], fmaf(a_r, ua, b_r), acc1[mq][i][0][c] + bv1[c]);
+          v[8 + c + 1] = fmaf(gv1[c + 1], fmaf(a_r, ub, b_r), acc1[mq][i][0][c + 1] + bv1[c + 1]);
+        }
+        // statistics of the row over this wave's 48 columns (4 lanes x 12), fixed order
+        float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11]));
+        sm += __shfl_xor(sm, 16);
+        sm += __shfl_xor(sm, 32);
+        const float mean = sm * (1.f / 48.f);
+        float qd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const float d = v[k] - mean; qd = fmaf(d, d, qd); }
+        qd += __shfl_xor(qd, 16);
+        qd += __shfl_xor(qd, 32);
+        const u32x2 pm = {__float_as_uint(mean), __float_as_uint(qd)};
+        const u32x4 o0 = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
+        const u32x2 o1 = {pack2<F16>(v[8], v[9]), pack2<F16>(v[10], v[11])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rc, ro == OOB ? OOB : (ro + (unsigned)col0) * 2u, 0, VTC_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(o1, rc, ro == OOB ? OOB : (ro + (unsigned)col1) * 2u, 0, VTC_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (unsigned)row * 128u + part_col, 0, 0);
+      }
+    } else {
+    [[maybe_unused]] float ln_mu[8], ln_rs[8], cs0[8], cs1[W1];
+    if constexpr (EPI & EPI_LNIN) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rstat, rowidx[g] == OOB ? OOB : rowidx[g] * 8u, 0, 0);
+        ln_mu[g] = __uint_as_float(t[0]); ln_rs[g] = __uint_as_float(t[1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 t = *(const float4*)(p.colsum + col0 + 4 * q);
+        cs0[4 * q] = t.x; cs0[4 * q + 1] = t.y; cs0[4 * q + 2] = t.z; cs0[4 * q + 3] = t.w;
+      }
+#pragma unroll
+      for (int q = 0; q < NJ1; ++q) {
+        const float4 t = *(const float4*)(p.colsum + col1 + 4 * q);
+        cs1[4 * q] = t.x; cs1[4 * q + 1] = t.y; cs1[4 * q + 2] = t.z; cs1[4 * q + 3] = t.w;
+      }
+      // wait for all of them now, while only loads are pending (see EPI_LNRES above): a first use behind the first
+      // store would be a full drain
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(ln_mu[g]), "v"(ln_rs[g]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(cs0[k]));
+#pragma unroll
+      for (int k = 0; k < W1; ++k) asm volatile("" ::"v"(cs1[k]));
     }
 #ifdef VTC_ABL_NOSTORE   // tools/gemm_bench ablation: every store is dropped by the bounds check
 #define VTC_OFF_ST(g, col, sz) OOB
@@ -370,14 +491,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     for (int g = 0; g < 8; ++g) {
       const int mq = g >> 2, i = g & 3;
       float v0[8], v1[W1];
+      if constexpr (EPI & EPI_LNIN) {   // LN(u) W^T + b = rstd * (u W'^T - mean * colsum) + b'
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v0[4 * j + r] = acc0[mq][i][j][r] + bv0[4 * j + r];
+          for (int r = 0; r < 4; ++r)
+            v0[4 * j + r] = fmaf(ln_rs[g], fmaf(-ln_mu[g], cs0[4 * j + r], acc0[mq][i][j][r]), bv0[4 * j + r]);
 #pragma unroll
-      for (int j = 0; j < NJ1; ++j)
+        for (int j = 0; j < NJ1; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v1[4 * j + r] = acc1[mq][i][j][r] + bv1[4 * j + r];
+          for (int r = 0; r < 4; ++r)
+            v1[4 * j + r] = fmaf(ln_rs[g], fmaf(-ln_mu[g], cs1[4 * j + r], acc1[mq][i][j][r]), bv1[4 * j + r]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v0[4 * j + r] = acc0[mq][i][j][r] + bv0[4 * j + r];
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v1[4 * j + r] = acc1[mq][i][j][r] + bv1[4 * j + r];
+      }
       if constexpr (EPI & EPI_GELU) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v0[k] = gelu_f(v0[k]);
@@ -421,6 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
       }
     }
+    }   // !EPI_LNRES
 #undef VTC_OFF_ST
 #undef VTC_OFF_LD
     VTC_STAMP(3);

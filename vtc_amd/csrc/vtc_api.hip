@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vtc_amd.h"
@@ -57,9 +58,13 @@ constexpr int kMaxDevices = 64;
 unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU
 std::mutex g_scratch_mu;
 
+// Device weights of one transformer layer in the LayerNorm-free form (gemm256.cuh): the LayerNorm in front of a GEMM is
+// folded into it (gamma into the 16-bit weights, beta into the bias, colsum for the mean), the LayerNorm behind a residual
+// add is applied by the epilogue that adds the residual (its gamma as res_g, its beta folded into that GEMM's bias).
 struct LayerDev {
   h16 *qkv_w, *o_w, *ff1_w, *ff2_w;
-  float *qkv_b, *o_b, *ff1_b, *ff2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  float *qkv_b, *qkv_s, *o_bb, *ff1_b, *ff1_s, *ff2_bb;
+  float *g_in, *ln1_w, *ln1_b, *ln2_w, *ln2_b;   // g_in: gamma of the LayerNorm that feeds the layer (previous ln2 / encoder LN)
 };
 
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
@@ -84,6 +89,7 @@ struct vtc_model {
 
   // workspace
   h16 *actA = nullptr, *actB = nullptr, *x16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffn16 = nullptr, *posin = nullptr;
+  float *ln_stats = nullptr, *ln_part = nullptr;   // per-row (mean, rstd); the 16 partial (mean, M2) pairs per row behind them
   float *h0 = nullptr, *tmp32 = nullptr, *gn_scale = nullptr, *gn_shift = nullptr, *c0_xscale = nullptr;
   _Float16* c0_aop = nullptr;   // conv0 MFMA operand (B, 512, 32), written per batch by the GroupNorm finalize kernel
   int* c0_flag = nullptr;
@@ -123,7 +129,6 @@ struct vtc_model {
   std::mutex resample_mu;                // vtc_prepare_audio is called from several reader threads
   bool prof_on = false;
   bool conv0_mfma = true;  // conv0 as one fp16-split MFMA per 16 x 16 outputs (env VTC_CONV0_MFMA=0: VALU form)
-  bool pre_ln16 = false;   // pre-LayerNorm rows of the transformer layers in 16 bit (default: on for fp16; env VTC_PRE_LN16)
   std::vector<ProfRec> prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_next = 0;
@@ -165,6 +170,37 @@ unsigned short host_to_h16(float x, bool f16) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+float host_from_h16(unsigned short v, bool f16) {
+  if (f16) { _Float16 h; memcpy(&h, &v, 2); return (float)h; }
+  const unsigned u = (unsigned)v << 16;
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+
+// A linear layer behind a LayerNorm, folded: W'[n][k] = W[n][k] * gamma[k] (* scale for the first scale_rows rows) rounded to
+// 16 bit; colsum[n] = sum_k W'[n][k] of the ROUNDED weights (it multiplies the row mean, which must cancel against what the
+// MFMA accumulated with those weights); bias'[n] = (b[n] + sum_k beta[k] W[n][k]) * scale, exact weights, fp64 sums.
+struct FoldedLinear { std::vector<unsigned short> w; std::vector<float> colsum, bias; };
+FoldedLinear fold_layernorm(const float* w, const float* b, int N, int K, const float* gamma, const float* beta, bool f16,
+                            float scale = 1.f, int scale_rows = 0) {
+  FoldedLinear out;
+  out.w.resize((size_t)N * K); out.colsum.resize(N); out.bias.resize(N);
+  for (int n = 0; n < N; ++n) {
+    const float sc = n < scale_rows ? scale : 1.f;
+    double cs = 0.0, bb = b[n];
+    for (int k = 0; k < K; ++k) {
+      const unsigned short h = host_to_h16(w[(size_t)n * K + k] * gamma[k] * sc, f16);
+      out.w[(size_t)n * K + k] = h;
+      cs += (double)host_from_h16(h, f16);
+      bb += (double)beta[k] * (double)w[(size_t)n * K + k];
+    }
+    out.colsum[n] = (float)cs;
+    out.bias[n] = (float)(bb * sc);
+  }
+  return out;
 }
 
 template <typename T>
@@ -250,6 +286,24 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   // 2 GiB (large batches of short windows: conv1 at batch 512 x 4 s is 3.3 GB) is cut into row chunks of whole
   // windows, each its own launch over the same weights.
   constexpr long long kEsz = (EPI & EPI_F32) ? 4 : 2;
+  if constexpr ((EPI & (EPI_LNIN | EPI_LNRES)) != 0) {
+    // LayerNorm-free layer GEMMs exist in the persistent kernel only (any M; N % 192 == 0 and K % 128 == 0 hold for
+    // 768 / 2304 / 3072).  Outputs beyond 2 GiB are cut into row chunks; every per-row array moves with the chunk.
+    const long long rows_max = (((1ll << 31) - 1) / ((long long)p.ldc * kEsz)) / 256 * 256;
+    for (long long r0 = 0; r0 < p.M; r0 += rows_max) {
+      GemmParams q = p;
+      q.M = (int)std::min<long long>(rows_max, p.M - r0);
+      q.rows_per_batch = q.M;
+      q.A = p.A + r0 * p.a_row_stride;
+      q.C = (char*)p.C + r0 * p.ldc * kEsz;
+      q.ln_stats = p.ln_stats + r0 * 2;
+      if (p.res_h) q.res_h = p.res_h + r0 * p.ldc;
+      if (p.part) q.part = p.part + r0 * 32;
+      const double fl = 2.0 * q.M * (double)p.N * p.K;
+      LAUNCH(m, PC_GEMM, fl, 0.0, s, (launch_gemm256<F16, EPI, 192>(q, 1, s)));
+    }
+    return;
+  } else {
   if (BN == 128 && m->big_tiles && p.K % 128 == 0 && p.K >= 256 && p.M >= 4096 && nz == 1 &&
       (long long)p.M * p.ldc * kEsz >= (1ll << 31)) {
     const long long unit = p.rows_per_batch < p.M ? p.rows_per_batch : 256;       // rows that may start a chunk
@@ -274,10 +328,14 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
     const long long tm = (p.M + 255) / 256;
     const long long c256 = p.N % 256 == 0 ? ((tm * (p.N / 256) * nz + 255) / 256) * 256 : -1;
     const long long c192 = p.N % 192 == 0 ? ((tm * (p.N / 192) * nz + 255) / 256) * 192 : -1;
+    static const int force_bn = getenv("VTC_GEMM_BN") ? atoi(getenv("VTC_GEMM_BN")) : 0;   // A/B runs: 192 or 256 where N allows
+    if (force_bn == 256 && c256 > 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
+    if (force_bn == 192 && c192 > 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
     if (c256 > 0 && (c192 < 0 || 100 * c192 > 102 * c256)) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 256>(p, nz, s))); return; }
     if (c192 > 0) { LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm256<F16, EPI, 192>(p, nz, s))); return; }
   }
   LAUNCH(m, PC_GEMM, flops, 0.0, s, (launch_gemm<F16, BN, EPI>(p, nz, s)));
+  }
 }
 
 GemmParams plain(const h16* A, const h16* W, void* C, const float* bias, const float* resid, int M, int N, int K) {
@@ -343,52 +401,51 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   LAUNCH(m, PC_GEMM, 2.0 * M * 768.0 * 48 * 128, 0.0, s,
          hipLaunchKernelGGL((posconv_kernel<F16>), dim3((T + kPcRows - 1) / kPcRows, 16, nw), dim3(256), 0, s, m->posin,
                             m->pos_w, m->pos_b, m->h0, m->tmp32, T));
+  // ---- entry of the LayerNorm-free layers: the fp32 pre-LN rows rounded to 16 bit + the statistics of the encoder LayerNorm
   HeadParams nohead{};
-  LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 10, s,
-         hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), dim3((M + 4 * kLnRows - 1) / (4 * kLnRows)), dim3(256), 0, s, (const void*)m->tmp32, m->enc_ln_w,
-                            m->enc_ln_b, (float*)nullptr, m->x16, M, nohead));
-  if (m->debug_stop == 8) return 0;
+  const dim3 ln_grid((M + 4 * kLnRows - 1) / (4 * kLnRows)), ln_blk(256);
+  LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 6, s,
+         hipLaunchKernelGGL((ln_round_stats_kernel<F16>), dim3((M + 3) / 4), dim3(256), 0, s, m->tmp32, m->x16, m->ln_stats, M));
+  // test hook: materialise LayerNorm(u) (what the oracle calls the stage output) in ctx16, which is free between layers
+  auto debug_ln = [&](const float* g, const float* b) {
+    hipLaunchKernelGGL((layernorm768_kernel<F16, false, 1>), ln_grid, ln_blk, 0, s, (const void*)m->x16, g, b,
+                       (float*)nullptr, m->ctx16, M, nohead);
+  };
+  if (m->debug_stop == 8) { debug_ln(m->enc_ln_w, m->enc_ln_b); return 0; }
 
   // ---- 12 post-LN transformer layers
   const int nkt = (T + 63) / 64;                       // 64-key tiles streamed through LDS
   const int nqb = ((T + 31) / 32 + kAttnWaves - 1) / kAttnWaves;   // blocks of 8 x 32 queries
   const double attn_flops = 4.0 * (double)nw * 12 * (double)T * T * 64;
+  auto ln_in_gemm = [&](auto epi, const h16* W, void* C, const float* bias, const float* colsum, int N) {
+    GemmParams p = plain(m->x16, W, C, bias, nullptr, M, N, 768);
+    p.ln_stats = m->ln_stats; p.colsum = colsum;
+    gemm_go<F16, 128, decltype(epi)::value>(m, p, 1, s);
+  };
+  auto ln_res_gemm = [&](const h16* A, const h16* W, const float* bias, const float* gamma, int K) {
+    GemmParams p = plain(A, W, m->x16, bias, nullptr, M, 768, K);
+    p.ln_stats = m->ln_stats; p.res_h = m->x16; p.res_g = gamma; p.part = m->ln_part;
+    gemm_go<F16, 128, EPI_BIAS | EPI_LNRES>(m, p, 1, s);
+    LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 136, s,
+           hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, m->ln_part, m->ln_stats, M));
+  };
   for (int l = 0; l < VTC_N_LAYERS; ++l) {
     const LayerDev& w = m->layer[l];
-    gemm_go<F16, 128, EPI_BIAS>(m, plain(m->x16, w.qkv_w, m->qkv16, w.qkv_b, nullptr, M, 2304, 768), 1, s);
+    ln_in_gemm(std::integral_constant<int, EPI_BIAS | EPI_LNIN>{}, w.qkv_w, m->qkv16, w.qkv_b, w.qkv_s, 2304);
     LAUNCH(m, PC_ATTN, attn_flops, 0.0, s,
            hipLaunchKernelGGL((attention_kernel<F16>), dim3(nqb, nw * 12), dim3(512), 0, s, m->qkv16, m->ctx16, T, nkt));
-    // out-proj / FFN2 add the 16-bit residual in the epilogue and hand the pre-LayerNorm rows to LN768, either
-    // as fp32 (tmp32) or, with pre_ln16, rounded to 16 bit (half the store burst and half the LN read)
-    auto resid_gemm = [&](const h16* A, const h16* W, const float* b, int K) {
-      if (m->pre_ln16)
-        gemm_go<F16, 128, EPI_BIAS | EPI_RESID16>(m, plain(A, W, m->tmp32, b, (const float*)m->x16, M, 768, K), 1, s);
-      else
-        gemm_go<F16, 128, EPI_BIAS | EPI_RESID16 | EPI_F32>(m, plain(A, W, m->tmp32, b, (const float*)m->x16, M, 768, K), 1, s);
-    };
-    auto ln768 = [&](const float* g, const float* b, bool head) {
-      const double bytes = (double)M * 768 * (m->pre_ln16 ? 4 : 6);
-      HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
-      const dim3 grid((M + 4 * kLnRows - 1) / (4 * kLnRows)), blk(256);
-      if (head) {   // final LayerNorm with the per-frame multi-label head fused; writes stitched logits
-        if (m->pre_ln16)
-          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, true, true>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, hp));
-        else
-          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, true, false>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, hp));
-      } else {
-        if (m->pre_ln16)
-          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, false, true>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, nohead));
-        else
-          LAUNCH(m, PC_LAYERNORM, 0.0, bytes, s, hipLaunchKernelGGL((layernorm768_kernel<F16, false, false>), grid, blk, 0, s, (const void*)m->tmp32, g, b, (float*)nullptr, m->x16, M, nohead));
-      }
-    };
-    resid_gemm(m->ctx16, w.o_w, w.o_b, 768);
-    ln768(w.ln1_w, w.ln1_b, false);
-    gemm_go<F16, 128, EPI_BIAS | EPI_GELU>(m, plain(m->x16, w.ff1_w, m->ffn16, w.ff1_b, nullptr, M, 3072, 768), 1, s);
-    resid_gemm(m->ffn16, w.ff2_w, w.ff2_b, 3072);
-    const bool last = l == VTC_N_LAYERS - 1;
-    ln768(w.ln2_w, w.ln2_b, last && m->debug_stop != 9 + l);
-    if (m->debug_stop == 9 + l) return 0;
+    ln_res_gemm(m->ctx16, w.o_w, w.o_bb, w.g_in, 768);          // u1 = LN_in(u) + ctx W_o^T + b_o, statistics of ln1
+    ln_in_gemm(std::integral_constant<int, EPI_BIAS | EPI_GELU | EPI_LNIN>{}, w.ff1_w, m->ffn16, w.ff1_b, w.ff1_s, 3072);
+    ln_res_gemm(m->ffn16, w.ff2_w, w.ff2_bb, w.ln1_w, 3072);    // u2 = LN_1(u1) + h W_2^T + b_2, statistics of ln2
+    if (m->debug_stop == 9 + l) { debug_ln(w.ln2_w, w.ln2_b); return 0; }
+  }
+  // ---- final LayerNorm with the per-frame multi-label head fused; writes stitched logits
+  {
+    const LayerDev& w = m->layer[VTC_N_LAYERS - 1];
+    HeadParams hp{m->head_w, m->head_b, logits, m->spec.n_labels, T, wt};
+    LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 768 * 2, s,
+           hipLaunchKernelGGL((layernorm768_kernel<F16, true, 1>), ln_grid, ln_blk, 0, s, (const void*)m->x16, w.ln2_w, w.ln2_b,
+                              (float*)nullptr, (h16*)nullptr, M, hp));
   }
   return 0;
 }
@@ -477,9 +534,7 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   m->spec = *spec;
   m->device = device;
   m->f16 = spec->mfma_dtype == 1;
-  m->pre_ln16 = m->f16;   // fp16 keeps 11 significand bits; bf16 rows stay fp32 ahead of LayerNorm
   if (const char* e = getenv("VTC_GEMM_TILE")) m->big_tiles = atoi(e) != 128;
-  if (const char* e = getenv("VTC_PRE_LN16")) m->pre_ln16 = atoi(e) != 0;
   if (const char* e = getenv("VTC_CONV0_MFMA")) m->conv0_mfma = atoi(e) != 0;
   m->T = (int)T;
   {
@@ -522,25 +577,40 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
     LayerDev& d = m->layer[l];
     if (!s.q_w || !s.k_w || !s.v_w || !s.q_b || !s.k_b || !s.v_b || !s.o_w || !s.ff1_w || !s.ff2_w)
       return bail(fail(m, VTC_ERR_ARG, "missing weight in layer %d", l));
-    // fused QKV [2304][768]; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e) of the
-    // softmax's exp2 form (attention.cuh) are folded into the query rows
+    if (!s.o_b || !s.ln1_w || !s.ln1_b || !s.ff1_b || !s.ff2_b || !s.ln2_w || !s.ln2_b)
+      return bail(fail(m, VTC_ERR_ARG, "missing bias / LayerNorm tensor in layer %d", l));
+    // LayerNorm that feeds this layer: the previous layer's final_layer_norm, the encoder's input LayerNorm for layer 0
+    const float* g_in = l == 0 ? w->enc_ln_w : w->layer[l - 1].ln2_w;
+    const float* b_in = l == 0 ? w->enc_ln_b : w->layer[l - 1].ln2_b;
+    if (!g_in || !b_in) return bail(fail(m, VTC_ERR_ARG, "missing LayerNorm in front of layer %d", l));
+    // fused QKV [2304][768] behind that LayerNorm; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e)
+    // of the softmax's exp2 form (attention.cuh) are folded into the query rows
     const float kQScale = 0.125f * 1.4426950408889634f;
-    std::vector<unsigned short> qkv = pack_linear(s.q_w, 768, 768, f16, kQScale, 768);
-    std::vector<unsigned short> kk = pack_linear(s.k_w, 768, 768, f16), vv = pack_linear(s.v_w, 768, 768, f16);
-    qkv.insert(qkv.end(), kk.begin(), kk.end());
-    qkv.insert(qkv.end(), vv.begin(), vv.end());
-    TRY(upload_h16(m, &d.qkv_w, qkv));
-    std::vector<float> qb(2304);
-    for (int i = 0; i < 768; ++i) { qb[i] = s.q_b[i] * kQScale; qb[768 + i] = s.k_b[i]; qb[1536 + i] = s.v_b[i]; }
-    TRY(upload_f32(m, &d.qkv_b, qb.data(), 2304));
+    std::vector<float> wq((size_t)2304 * 768), bq(2304);
+    memcpy(&wq[0], s.q_w, sizeof(float) * 768 * 768);
+    memcpy(&wq[(size_t)768 * 768], s.k_w, sizeof(float) * 768 * 768);
+    memcpy(&wq[(size_t)1536 * 768], s.v_w, sizeof(float) * 768 * 768);
+    memcpy(&bq[0], s.q_b, sizeof(float) * 768);
+    memcpy(&bq[768], s.k_b, sizeof(float) * 768);
+    memcpy(&bq[1536], s.v_b, sizeof(float) * 768);
+    const FoldedLinear fq = fold_layernorm(wq.data(), bq.data(), 2304, 768, g_in, b_in, f16, kQScale, 768);
+    TRY(upload_h16(m, &d.qkv_w, fq.w));
+    TRY(upload_f32(m, &d.qkv_b, fq.bias.data(), 2304));
+    TRY(upload_f32(m, &d.qkv_s, fq.colsum.data(), 2304));
+    TRY(upload_f32(m, &d.g_in, g_in, 768));
+    // out-proj adds the residual LN_in(u): its beta joins the bias
     TRY(upload_h16(m, &d.o_w, pack_linear(s.o_w, 768, 768, f16)));
-    TRY(upload_f32(m, &d.o_b, s.o_b, 768));
+    std::vector<float> obb(768), f2bb(768);
+    for (int i = 0; i < 768; ++i) { obb[i] = s.o_b[i] + b_in[i]; f2bb[i] = s.ff2_b[i] + s.ln1_b[i]; }
+    TRY(upload_f32(m, &d.o_bb, obb.data(), 768));
     TRY(upload_f32(m, &d.ln1_w, s.ln1_w, 768));
     TRY(upload_f32(m, &d.ln1_b, s.ln1_b, 768));
-    TRY(upload_h16(m, &d.ff1_w, pack_linear(s.ff1_w, 3072, 768, f16)));
-    TRY(upload_f32(m, &d.ff1_b, s.ff1_b, 3072));
+    const FoldedLinear f1 = fold_layernorm(s.ff1_w, s.ff1_b, 3072, 768, s.ln1_w, s.ln1_b, f16);
+    TRY(upload_h16(m, &d.ff1_w, f1.w));
+    TRY(upload_f32(m, &d.ff1_b, f1.bias.data(), 3072));
+    TRY(upload_f32(m, &d.ff1_s, f1.colsum.data(), 3072));
     TRY(upload_h16(m, &d.ff2_w, pack_linear(s.ff2_w, 768, 3072, f16)));
-    TRY(upload_f32(m, &d.ff2_b, s.ff2_b, 768));
+    TRY(upload_f32(m, &d.ff2_bb, f2bb.data(), 768));
     TRY(upload_f32(m, &d.ln2_w, s.ln2_w, 768));
     TRY(upload_f32(m, &d.ln2_b, s.ln2_b, 768));
   }
@@ -554,6 +624,8 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   TRY(dev_alloc(m, &m->h0, MT * 768));
   TRY(dev_alloc(m, &m->tmp32, MT * 768));
   TRY(dev_alloc(m, &m->x16, MT * 768));
+  TRY(dev_alloc(m, &m->ln_stats, MT * 2));
+  TRY(dev_alloc(m, &m->ln_part, MT * 32));
   TRY(dev_alloc(m, &m->qkv16, MT * 2304));
   TRY(dev_alloc(m, &m->ctx16, MT * 768));
   TRY(dev_alloc(m, &m->ffn16, MT * 3072));
@@ -1076,7 +1148,7 @@ int64_t vtc_debug_stage(vtc_model* m, int32_t stage, int32_t nw, float* out, int
   bool is16 = true;
   if (stage >= 0 && stage <= 6) { src = (stage % 2 == 0) ? m->actA : m->actB; n = (long long)nw * m->L[stage] * 512; }
   else if (stage == 7) { src = m->h0; n = (long long)nw * m->T * 768; is16 = false; }
-  else if (stage >= 8 && stage < 9 + VTC_N_LAYERS) { src = m->x16; n = (long long)nw * m->T * 768; }
+  else if (stage >= 8 && stage < 9 + VTC_N_LAYERS) { src = m->ctx16; n = (long long)nw * m->T * 768; }   // debug_ln's output
   else return fail(m, VTC_ERR_ARG, "unknown stage %d", stage);
   if (n > cap) return fail(m, VTC_ERR_CAPACITY, "stage %d needs %lld floats", stage, n);
   if (!is16) {
