@@ -95,7 +95,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int lr = lane >> 3, lc = lane & 7;
   const int fr = lane & 15, fq = lane >> 4;
   const int z = blockIdx.y;
   const unsigned ntiles = (unsigned)(p.tiles_m * p.tiles_n);
@@ -107,6 +106,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const char* src_b1[NJ1];
 
   auto set_sources = [&](int tile_m, int tile_n) {
+    // lane-derived values are recomputed here from an opaque copy of the thread id: kept live across the K loop they cost
+    // ~12 registers the 256-wide variant does not have (they were spilled and reloaded behind a vmcnt(0) every tile)
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int lr = (t_ & 63) >> 3, lc = t_ & 7, wave = t_ >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (wave * 2 + i) * 8 + lr;  // row inside a 128-row half-tile
