@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
   const int only_tile = argc > 3 ? atoi(argv[3]) : 0;
   std::vector<Shape> shapes = {
       {"conv1  M=1.02M N=512  K=1536 (implicit)", 64 * 15999, 512, 1536, 15999, 1024, 31999LL * 512, EPI_GELU},
+      {"conv1c M=1.02M N=512  K=1536 (implicit, A cache-resident: windows 1 row apart)", 64 * 15999, 512, 1536, 15999, 1024, 1024LL, EPI_GELU},
       {"conv2  M=512K  N=512  K=1536 (implicit)", 64 * 7999, 512, 1536, 7999, 1024, 15999LL * 512, EPI_GELU},
       {"conv5  M=64K   N=512  K=1024 (implicit)", 64 * 999, 512, 1024, 999, 1024, 1999LL * 512, EPI_GELU},
       {"qkv    M=31936 N=2304 K=768", 31936, 2304, 768, 31936, 768, 0, EPI_BIAS},

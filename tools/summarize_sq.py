@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc passes with SQ / GRBM counters into one JSON: per kernel (all launches of a pass averaged) every
+counter per launch, plus derived figures that can be set beside DESIGN.md's in-loop estimates:
+  mfma_busy_frac      = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4)   (cycles a SIMD's matrix pipe was busy / SIMD-cycles
+                        of busy CUs; both are summed over the chip)
+  wait_frac           = SQ_WAIT_ANY / SQ_WAVE_CYCLES                         (wave-cycles parked on s_waitcnt / barriers)
+  lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  eff_clock_ghz       = GRBM_GUI_ACTIVE / 8 / average kernel time            (MI355X_MICROARCH.md, DVFS give-back)
+usage: summarize_sq.py KERNEL_STATS.csv OUT.json PASS1.csv [PASS2.csv ...]"""
+import collections, csv, json, sys
+
+stats = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(sys.argv[1]))}
+agg = collections.OrderedDict()
+for path in sys.argv[3:]:
+    for r in csv.DictReader(open(path)):
+        d = agg.setdefault(r["Kernel_Name"], collections.defaultdict(list))
+        d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = []
+for k, d in agg.items():
+    c = {n: sum(v) / len(v) for n, v in d.items()}
+    row = {"kernel": k, "launches_profiled": max(len(v) for v in d.values()), "avg_ns": stats.get(k), "per_launch": c}
+    g = c.get
+    if g("SQ_BUSY_CU_CYCLES"):
+        row["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+    if g("SQ_WAVE_CYCLES"):
+        row["wait_frac"] = g("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        row["issue_stall_frac"] = g("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+    if g("SQ_LDS_IDX_ACTIVE"):
+        row["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    if g("GRBM_GUI_ACTIVE") and stats.get(k):
+        row["eff_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / stats[k]
+    out.append(row)
+out.sort(key=lambda r: -(r["avg_ns"] or 0) * r["launches_profiled"])
+json.dump({"note": "rocprofv3 --pmc, separate passes over bench.py --steps 2 --warmup 1 (counter values are chip-wide sums per launch, "
+                   "averaged over the launches of the pass); avg_ns from the --kernel-trace --stats pass", "kernels": out},
+          open(sys.argv[2], "w"), indent=1)
+print("wrote", sys.argv[2], len(out), "kernels")

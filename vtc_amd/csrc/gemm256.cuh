@@ -108,9 +108,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   auto set_sources = [&](int tile_m, int tile_n) {
     // lane-derived values are recomputed here from an opaque copy of the thread id: kept live across the K loop they cost
     // ~12 registers the 256-wide variant does not have (they were spilled and reloaded behind a vmcnt(0) every tile)
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-    const int lr = (t_ & 63) >> 3, lc = t_ & 7, wave = t_ >> 6;
+    int l_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));   // lane id, never hoisted
+    const int lr = l_ >> 3, lc = l_ & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (wave * 2 + i) * 8 + lr;  // row inside a 128-row half-tile
