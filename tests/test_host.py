@@ -336,6 +336,45 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert all(o["slowest"] == 2.0 and o["total"] == 11 for o in outs)
 
 
+def test_xlsx_manifest(tmp_path):
+    """.xlsx manifests (reference src/utils.py:305-312 reads them through polars/openpyxl): a hand-made workbook with shared
+    strings, an inline string, numbers, an empty cell and a second sheet that must be ignored."""
+    import zipfile
+    from vtc_amd import utils
+    ns = 'xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main"'
+    rel = 'xmlns:r="http://schemas.openxmlformats.org/officeDocument/2006/relationships"'
+    sheet = (f'<worksheet {ns}><sheetData>'
+             '<row r="1"><c r="A1" t="s"><v>0</v></c><c r="B1" t="s"><v>1</v></c><c r="C1" t="s"><v>2</v></c></row>'
+             '<row r="2"><c r="A2" t="s"><v>3</v></c><c r="B2"><v>12.5</v></c><c r="C2" t="s"><v>5</v></c></row>'
+             '<row r="3"><c r="A3" t="inlineStr"><is><t>/data/b.flac</t></is></c><c r="B3"><v>7</v></c></row>'
+             '<row r="4"><c r="A4" t="s"><v>4</v></c><c r="C4" t="str"><v>x</v></c></row>'
+             '</sheetData></worksheet>')
+    other = f'<worksheet {ns}><sheetData><row r="1"><c r="A1" t="inlineStr"><is><t>nope</t></is></c></row></sheetData></worksheet>'
+    shared = (f'<sst {ns}><si><t>path</t></si><si><t>duration</t></si><si><t>note</t></si><si><t>/data/a.wav</t></si>'
+              '<si><r><t>/data/</t></r><r><t>c.wav</t></r></si><si><t>ok</t></si></sst>')
+    wb = (f'<workbook {ns} {rel}><sheets><sheet name="files" sheetId="7" r:id="rId2"/><sheet name="x" sheetId="1" r:id="rId1"/>'
+          '</sheets></workbook>')
+    rels = ('<Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">'
+            '<Relationship Id="rId1" Target="worksheets/sheet1.xml" Type="t"/>'
+            '<Relationship Id="rId2" Target="worksheets/sheet2.xml" Type="t"/></Relationships>')
+    with zipfile.ZipFile(tmp_path / "m.xlsx", "w") as z:
+        z.writestr("xl/workbook.xml", wb)
+        z.writestr("xl/_rels/workbook.xml.rels", rels)
+        z.writestr("xl/sharedStrings.xml", shared)
+        z.writestr("xl/worksheets/sheet1.xml", other)
+        z.writestr("xl/worksheets/sheet2.xml", sheet)
+    t = utils.load_manifest(tmp_path / "m.xlsx")
+    assert t.column_names == ["path", "duration", "note"]
+    assert utils.manifest_paths(t) == ["/data/a.wav", "/data/b.flac", "/data/c.wav"]
+    assert t.column("duration").to_pylist() == [12.5, 7, None] and t.column("note").to_pylist() == ["ok", None, "x"]
+    (tmp_path / "bad.xlsx").write_bytes(b"not a zip")
+    with pytest.raises(RuntimeError, match="Failed to read Excel"):
+        utils.load_manifest(tmp_path / "bad.xlsx")
+    (tmp_path / "old.xls").write_bytes(b"\xd0\xcf\x11\xe0")
+    with pytest.raises(RuntimeError, match="xls"):
+        utils.load_manifest(tmp_path / "old.xls")
+
+
 def test_batch_size_recommendation():
     """reference src/pipeline/resources.py:180-196 for 4 s windows; scaled by the window length for other configs."""
     from vtc_amd.pipeline.vtc import recommend_vtc_batch_size as rec

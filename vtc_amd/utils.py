@@ -28,7 +28,7 @@ import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
 
-MANIFEST_EXTENSIONS = [".parquet", ".csv", ".tsv", ".json", ".jsonl"]
+MANIFEST_EXTENSIONS = [".parquet", ".csv", ".tsv", ".xlsx", ".xls", ".json", ".jsonl"]   # src/utils.py:40-48
 BENCHMARK_LOG = Path("logs/benchmarks.jsonl")
 
 SEGMENT_SCHEMA = pa.schema([("uid", pa.string()), ("onset", pa.float64()), ("offset", pa.float64()),
@@ -106,7 +106,82 @@ def load_manifest(path: Path) -> pa.Table:
     if suffix == ".json":
         with open(path) as f:
             return pa.Table.from_pylist(json.load(f))
+    if suffix == ".xlsx":
+        return _read_xlsx(path)
+    if suffix == ".xls":
+        # the reference hands .xls to polars -> xlrd (src/utils.py:305-312); the legacy BIFF container has no reader here
+        raise RuntimeError(f"Failed to read Excel file '{path}': legacy .xls (BIFF) is not supported, save it as .xlsx or .csv")
     raise ValueError(f"Unsupported manifest format '{suffix}'. Supported: {', '.join(MANIFEST_EXTENSIONS)}")
+
+
+def _read_xlsx(path) -> pa.Table:
+    """First worksheet of an .xlsx workbook as a table (reference: pl.read_excel, src/utils.py:305-312; openpyxl is not
+    needed: the container is a zip of XML parts).  First row = header; shared, inline and formula-cached strings, numbers and
+    booleans; empty cells become nulls.  A column whose cells are all numbers stays numeric, anything else is text."""
+    import re
+    import zipfile
+    import xml.etree.ElementTree as ET
+    ns = {"m": "http://schemas.openxmlformats.org/spreadsheetml/2006/main",
+          "r": "http://schemas.openxmlformats.org/officeDocument/2006/relationships",
+          "p": "http://schemas.openxmlformats.org/package/2006/relationships"}
+    try:
+        with zipfile.ZipFile(path) as z:
+            names = set(z.namelist())
+            shared = []
+            if "xl/sharedStrings.xml" in names:
+                for si in ET.fromstring(z.read("xl/sharedStrings.xml")).findall("m:si", ns):
+                    shared.append("".join(t.text or "" for t in si.iter("{%s}t" % ns["m"])))
+            sheet = "xl/worksheets/sheet1.xml"
+            if "xl/workbook.xml" in names and "xl/_rels/workbook.xml.rels" in names:     # the FIRST sheet in workbook order
+                wb = ET.fromstring(z.read("xl/workbook.xml"))
+                first = wb.find("m:sheets/m:sheet", ns)
+                rid = first.get("{%s}id" % ns["r"]) if first is not None else None
+                for rel in ET.fromstring(z.read("xl/_rels/workbook.xml.rels")).findall("p:Relationship", ns):
+                    if rel.get("Id") == rid:
+                        target = rel.get("Target").lstrip("/")
+                        sheet = target if target.startswith("xl/") else "xl/" + target
+            root = ET.fromstring(z.read(sheet))
+    except (zipfile.BadZipFile, KeyError, ET.ParseError) as e:
+        raise RuntimeError(f"Failed to read Excel file '{path}': {e}") from e
+
+    def col_index(ref: str) -> int:
+        n = 0
+        for ch in re.match(r"[A-Z]+", ref).group(0):
+            n = n * 26 + ord(ch) - 64
+        return n - 1
+
+    rows = []
+    for row in root.findall("m:sheetData/m:row", ns):
+        cells = {}
+        for k, c in enumerate(row.findall("m:c", ns)):
+            j = col_index(c.get("r")) if c.get("r") else k
+            t, v = c.get("t", "n"), c.find("m:v", ns)
+            if t == "inlineStr":
+                val = "".join(x.text or "" for x in c.iter("{%s}t" % ns["m"]))
+            elif v is None or v.text is None:
+                val = None
+            elif t == "s":
+                val = shared[int(v.text)]
+            elif t in ("str", "e"):
+                val = v.text
+            elif t == "b":
+                val = v.text == "1"
+            else:
+                f = float(v.text)
+                val = int(f) if f.is_integer() and "." not in v.text and "e" not in v.text.lower() else f
+            cells[j] = val
+        rows.append(cells)
+    if not rows:
+        return pa.table({})
+    width = max(max(r) for r in rows if r) + 1
+    header = [str(rows[0].get(j)) if rows[0].get(j) is not None else f"column_{j + 1}" for j in range(width)]
+    cols = {}
+    for j, name in enumerate(header):
+        vals = [r.get(j) for r in rows[1:]]
+        if any(isinstance(v, str) for v in vals):
+            vals = [None if v is None else (v if isinstance(v, str) else str(v)) for v in vals]
+        cols[name] = vals
+    return pa.table(cols)
 
 
 def manifest_paths(table: pa.Table, column: str = "path") -> list[str]:
