@@ -164,8 +164,8 @@ def spawn_check() -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--chunk", type=float, default=10.0)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
-#include "attention.cuh"
+#include "attention.hip.h"
 using namespace vtc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 

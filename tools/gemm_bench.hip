@@ -6,8 +6,8 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
-#include "gemm.cuh"
-#include "gemm256.cuh"
+#include "gemm.hip.h"
+#include "gemm256.hip.h"
 using namespace vtc;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)

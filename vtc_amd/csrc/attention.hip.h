@@ -16,7 +16,7 @@
 //   * online softmax over 64 keys per step; the running-max rescale of O is skipped when no query of the
 //     wave raised its maximum (exact, wave-uniform branch).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace vtc {
 

@@ -4,7 +4,7 @@
 // lowpass_filter_width 6, rolloff 0.99): a polyphase windowed-sinc filter, kernels computed in fp64 and applied in fp32.
 // HBM-bound streaming work: one thread per output sample, ~12 * max(1, sr_in/16000) taps each.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace vtc {
 

@@ -6,7 +6,7 @@
 // (i*320, j*320+400) samples (src/analysis/chunk_artifact.py:11-13,75-83) on the host side.
 // Three passes, deterministic: count run starts/ends per 256-frame block, exclusive scan, emit.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace vtc {
 

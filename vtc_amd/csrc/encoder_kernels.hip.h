@@ -4,7 +4,7 @@
 // :439-441 (encoder LN), :387-397 (post-LN layers); the reference names this stack at
 // src/analysis/chunk_artifact.py:40-48.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace vtc {
 
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const void* __restric
   }
 }
 
-// Entry of the LayerNorm-free transformer layers (gemm256.cuh): fp32 pre-LN rows (pos-conv output + residual) -> 16-bit
+// Entry of the LayerNorm-free transformer layers (gemm256.hip.h): fp32 pre-LN rows (pos-conv output + residual) -> 16-bit
 // rows and the row statistics (mean, rstd) of the encoder's input LayerNorm; one wave per row, two-pass.
 template <bool F16>
 __global__ __launch_bounds__(256) void ln_round_stats_kernel(const float* __restrict__ in, h16* __restrict__ out_h,

@@ -11,12 +11,12 @@
 // Global -> LDS by global_load_lds_dwordx4 (1 KiB per wave instruction, lane-linear LDS image);
 // the XOR swizzle lives on the per-lane SOURCE address and on the ds_read_b128 address.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace vtc {
 
 enum : int { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_F32 = 8, EPI_RESID16 = 16,   // RESID16: residual stored 16-bit
-             // LayerNorm-free transformer layers (gemm256 only; see gemm256.cuh "LayerNorm without a LayerNorm kernel"):
+             // LayerNorm-free transformer layers (gemm256 only; see gemm256.hip.h "LayerNorm without a LayerNorm kernel"):
              EPI_LNIN = 32,    // A holds PRE-LayerNorm rows; the normalisation is applied to the accumulators
              EPI_LNRES = 64 }; // residual = LayerNorm of 16-bit pre-LN rows; output = pre-LN rows + partial row statistics
 

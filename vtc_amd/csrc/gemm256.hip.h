@@ -1,5 +1,5 @@
 // Persistent 256 x BN x 64 MFMA GEMM (BN = 256 or 192), 8 waves, 8-phase schedule (two K-tiles per loop
-// iteration).  Same contract as gemm.cuh (C = A * W^T, overlapping-row A addressing, fused epilogues);
+// iteration).  Same contract as gemm.hip.h (C = A * W^T, overlapping-row A addressing, fused epilogues);
 // requires K % 128 == 0 and N % BN == 0 (W rows are read unguarded).
 //
 // Why: tools/gemm_bench ablations show the 128 x 128 kernel is bound by the L2 -> LDS fill (it runs as fast
@@ -39,8 +39,8 @@
 // first pass's stores (a full vmcnt(0) drain that waits for the store acknowledgements of the chip-wide output burst:
 // +33..45 us per launch) or ~100 more live registers than the kernel has (96 spilled).
 #pragma once
-#include "common.cuh"
-#include "gemm.cuh"
+#include "common.hip.h"
+#include "gemm.hip.h"
 
 namespace vtc {
 

@@ -8,8 +8,8 @@
 // weights (48 x 6144 per group, L2 resident) stream, 8 KiB per 64-deep K step, double buffered.
 // Block = 4 waves, wave tile 64 frames x 48 channels (4 x 3 MFMA 16x16x32 tiles).
 #pragma once
-#include "common.cuh"
-#include "gemm.cuh"
+#include "common.hip.h"
+#include "gemm.hip.h"
 
 namespace vtc {
 

@@ -14,15 +14,15 @@
 #include <vector>
 
 #include "../../include/vtc_amd.h"
-#include "attention.cuh"
-#include "audio_kernels.cuh"
-#include "common.cuh"
-#include "decode_kernels.cuh"
-#include "encoder_kernels.cuh"
+#include "attention.hip.h"
+#include "audio_kernels.hip.h"
+#include "common.hip.h"
+#include "decode_kernels.hip.h"
+#include "encoder_kernels.hip.h"
 #include "flac_decode.h"
-#include "gemm.cuh"
-#include "gemm256.cuh"
-#include "posconv.cuh"
+#include "gemm.hip.h"
+#include "gemm256.hip.h"
+#include "posconv.hip.h"
 
 using namespace vtc;
 
@@ -58,7 +58,7 @@ constexpr int kMaxDevices = 64;
 unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU
 std::mutex g_scratch_mu;
 
-// Device weights of one transformer layer in the LayerNorm-free form (gemm256.cuh): the LayerNorm in front of a GEMM is
+// Device weights of one transformer layer in the LayerNorm-free form (gemm256.hip.h): the LayerNorm in front of a GEMM is
 // folded into it (gamma into the 16-bit weights, beta into the bias, colsum for the mean), the LayerNorm behind a residual
 // add is applied by the epilogue that adds the residual (its gamma as res_g, its beta folded into that GEMM's bias).
 struct LayerDev {
@@ -586,7 +586,7 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
     const float* b_in = l == 0 ? w->enc_ln_b : w->layer[l - 1].ln2_b;
     if (!g_in || !b_in) return bail(fail(m, VTC_ERR_ARG, "missing LayerNorm in front of layer %d", l));
     // fused QKV [2304][768] behind that LayerNorm; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e)
-    // of the softmax's exp2 form (attention.cuh) are folded into the query rows
+    // of the softmax's exp2 form (attention.hip.h) are folded into the query rows
     const float kQScale = 0.125f * 1.4426950408889634f;
     std::vector<float> wq((size_t)2304 * 768), bq(2304);
     memcpy(&wq[0], s.q_w, sizeof(float) * 768 * 768);
