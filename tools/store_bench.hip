@@ -32,6 +32,60 @@ __global__ __launch_bounds__(512) void store_kernel(char* out, long long row_str
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// Epilogue-shaped stores of one 256 x 192 16-bit tile (96 KB per block, row stride as in the QKV output):
+//   MODE 0: as gemm256's C^T epilogue: per wave and row group a b128 (16 rows x 64 B) and a b64 (16 rows x 32 B)
+//   MODE 1: the same bytes as whole 128-B lines: the tile as [256 rows][384 B], 24 lanes x 16 B per row
+//   MODE 2: 64-B pieces only (16 rows x 64 B per instruction, 1.5 instructions' worth: the BN = 256 shape)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(512) void tile_store_kernel(char* out, long long row_stride, long long* cycles, int tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  const u32x4 v = {(unsigned)lane, 1u, 2u, 3u};
+  const u32x2 v2 = {(unsigned)lane, 1u};
+  __syncthreads();
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    char* base = out + ((long long)(blockIdx.x * tiles + t) * 256) * row_stride;
+    if (MODE == 0) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int row = (g >> 2) * 128 + wm * 64 + (g & 3) * 16 + fr;
+        *(u32x4*)(base + row * row_stride + (wn * 32 + 8 * fq) * 2) = v;
+        *(u32x2*)(base + row * row_stride + (128 + wn * 16 + 4 * fq) * 2) = v2;
+      }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int idx = (wave * 12 + k) * 64 + lane;
+        const int row = idx / 24, c = idx % 24;
+        *(u32x4*)(base + row * row_stride + c * 16) = v;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        const int row = ((g * 8 + wave) % 16) * 16 + fr;
+        *(u32x4*)(base + row * row_stride + (g / 2) * 64 + fq * 16) = v;
+      }
+    }
+  }
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime();      // all stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const long long t2 = (long long)__builtin_amdgcn_s_memtime();      // all stores acknowledged
+  if (threadIdx.x == 0) { cycles[blockIdx.x * 2] = t1 - t0; cycles[blockIdx.x * 2 + 1] = t2 - t0; }
+}
+
+template <int MODE> void run_tile(char* out, long long* cyc, int grid, int tiles) {
+  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((tile_store_kernel<MODE>), dim3(grid), dim3(512), 0, 0, out, 4608LL, cyc, tiles);
+  CK(hipDeviceSynchronize());
+  long long h[512]; CK(hipMemcpy(h, cyc, grid * 16, hipMemcpyDeviceToHost));
+  double a = 0, b = 0; for (int i = 0; i < grid; ++i) { a += h[2 * i]; b += h[2 * i + 1]; }
+  a /= grid; b /= grid;
+  printf("tile mode %d  grid %3d  tiles %d: issued after %7.0f cycles, acknowledged after %7.0f -> %.1f B/cycle/CU\n", MODE, grid, tiles, a, b,
+         tiles * 98304.0 / b);
+}
+
 template <int ROWS, int NST> void run(char* out, long long* cyc, int grid) {
   for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((store_kernel<ROWS, NST>), dim3(grid), dim3(512), 0, 0, out, 4608LL, cyc);
   CK(hipDeviceSynchronize());
@@ -43,7 +97,9 @@ template <int ROWS, int NST> void run(char* out, long long* cyc, int grid) {
 
 int main() {
   char* out; long long* cyc;
-  CK(hipMalloc(&out, 256LL * 256 * 4608 + (1 << 20))); CK(hipMalloc(&cyc, 256 * 8));
+  CK(hipMalloc(&out, 4LL * 256 * 256 * 4608 + (1 << 20))); CK(hipMalloc(&cyc, 512 * 8));
+  for (int grid : {256, 8})
+    for (int tiles : {1, 4}) { run_tile<0>(out, cyc, grid, tiles); run_tile<1>(out, cyc, grid, tiles); run_tile<2>(out, cyc, grid, tiles); }
   for (int grid : {256, 16}) {
     run<16, 16>(out, cyc, grid); run<8, 16>(out, cyc, grid); run<4, 16>(out, cyc, grid); run<2, 16>(out, cyc, grid); run<1, 16>(out, cyc, grid);
     run<16, 4>(out, cyc, grid); run<2, 4>(out, cyc, grid);

@@ -69,6 +69,24 @@ __device__ __forceinline__ float gelu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
 }
 
+// Two elements at once with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations
+// in the same order, so the results are bit-identical to gelu_f).  tools/gelu_bench: 15.8 ns of SIMD time per 64 elements
+// against 21.3; what is left is mostly the two quarter-rate transcendentals (8.9 ns).
+__device__ __forceinline__ void gelu2(float& a, float& b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 x = {a, b};
+  const f32x2 s = x * x;
+  f32x2 p = __builtin_elementwise_fma(f32x2{-3.2290622584696393e-06f, -3.2290622584696393e-06f}, s,
+                                      f32x2{8.823935058899224e-05f, 8.823935058899224e-05f});
+  p = __builtin_elementwise_fma(p, s, f32x2{0.0003602687211241573f, 0.0003602687211241573f});
+  p = __builtin_elementwise_fma(p, s, f32x2{-0.10522668063640594f, -0.10522668063640594f});
+  p = __builtin_elementwise_fma(p, s, f32x2{-2.3020453453063965f, -2.3020453453063965f});
+  const f32x2 z = x * p;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + f32x2{1.f, 1.f};
+  const f32x2 r = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  a = r[0]; b = r[1];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -190,8 +190,9 @@ __device__ __forceinline__ void conv0_valu_tile(float* xs /*[5*64+8]*/, const fl
         y0 = fmaf(w[c][j], x[j], y0);
         y1 = fmaf(w[c + 1][j], x[j], y1);
       }
-      y0 = gelu_f(fmaf(y0, sc[c], sh[c]));
-      y1 = gelu_f(fmaf(y1, sc[c + 1], sh[c + 1]));
+      y0 = fmaf(y0, sc[c], sh[c]);
+      y1 = fmaf(y1, sc[c + 1], sh[c + 1]);
+      gelu2(y0, y1);
       pk[c >> 1] = pack2<F16>(y0, y1);
     }
     *(uint4*)(out + ((long long)b * L0 + t) * 512 + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -277,8 +278,11 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mfma16<true>(af[q][j], bf, acc);   // rows: channels 16*fq' + 4j + r of the group, cols: frames
-        pk[2 * j] = pack2<true>(gelu_f(acc[0]), gelu_f(acc[1]));
-        pk[2 * j + 1] = pack2<true>(gelu_f(acc[2]), gelu_f(acc[3]));
+        float g0 = acc[0], g1 = acc[1], g2 = acc[2], g3 = acc[3];
+        gelu2(g0, g1);
+        gelu2(g2, g3);
+        pk[2 * j] = pack2<true>(g0, g1);
+        pk[2 * j + 1] = pack2<true>(g2, g3);
       }
       if (t < L0) {
         h16* dst = out + ((long long)b * L0 + t) * 512 + wave * 128 + q * 64 + 16 * fq;
@@ -439,14 +443,15 @@ __global__ __launch_bounds__(256) void ln_round_stats_kernel(const float* __rest
 // Row statistics from the 16 partials the EPI_LNRES epilogue left (each the mean and centred sum of squares of 48 columns):
 // equal group sizes, so mean = average of the group means and M2 = sum of the group M2 + 48 * sum (group mean - mean)^2
 // (Chan et al.), always in the same order: bit-reproducible.  One thread per row.
-__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows) {
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows,
+                                                                int part_rows) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
-  float mp[16], qp[16];
+  float mp[16], qp[16];   // part is [16 groups][part_rows][2]
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float4 t = *(const float4*)(part + (long long)row * 32 + i * 4);
-    mp[2 * i] = t.x; qp[2 * i] = t.y; mp[2 * i + 1] = t.z; qp[2 * i + 1] = t.w;
+  for (int i = 0; i < 16; ++i) {
+    const float2 t = *(const float2*)(part + ((long long)i * part_rows + row) * 2);
+    mp[i] = t.x; qp[i] = t.y;
   }
   float sm = 0.f, sq = 0.f;
 #pragma unroll

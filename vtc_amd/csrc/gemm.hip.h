@@ -42,7 +42,8 @@ struct GemmParams {
   const h16* res_h;          // LNRES: 16-bit pre-LN rows the residual is the LayerNorm of (may alias C: a lane reads exactly
                              //        the elements it later writes)
   const float* res_g;        // LNRES: [N] gamma of that LayerNorm (its beta is folded into bias)
-  float* part;               // LNRES: [M][16][2] (mean, M2) of the output row over 16 groups of 48 columns
+  float* part;               // LNRES: [16][part_rows][2] (mean, M2) of the output row over 16 groups of 48 columns; group-major, so
+  int part_rows;             //        the 16 rows x 8 B a wave writes at a time are one whole 128-B line
 };
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }

@@ -28,7 +28,7 @@
 // kept as 16-bit PRE-LayerNorm rows u (what the next GEMM reads as its A operand) plus per-row statistics (mean, rstd):
 //   EPI_LNRES (out-proj, FFN2):  v = acc + bias' + gamma_c * ((u - mean_r) * rstd_r)   [bias' = bias + beta]
 //       writes v (16 bit) and, per row, the (mean, M2) of the fp32 v over each wave's 48 columns: 16 partials per row in a
-//       fixed layout, merged in a fixed order by ln_stats_finalize_kernel, so the result is bit-reproducible (no atomics).
+//       fixed (group-major) layout, merged in a fixed order by ln_stats_finalize_kernel: bit-reproducible, no atomics.
 //   EPI_LNIN (QKV, FFN1):  LN(u) W^T + b = rstd_r * (u W'^T - mean_r * s_c) + b'  with W' = gamma o W rounded to 16 bit,
 //       s_c = sum_k W'[c][k] (of the rounded weights, so the mean cancels exactly), b' = b + W beta.
 // Rounding: the residual stream is rounded to 16 bit once per LayerNorm (u), where the LayerNorm-kernel form rounded
@@ -54,8 +54,8 @@ __device__ __forceinline__ int perm32(int rho) { return 8 * ((rho & 15) >> 2) + 
 #define VTC_STORE_AUX 0   // cache policy bits of the epilogue stores (tools/gemm_bench builds try others)
 #endif
 #ifdef VTC_STAMPS   // tools/gemm_bench diagnostic build: s_memtime stamps of the first two tiles of every block
-__device__ long long g_stamps[256 * 8];
-#define VTC_STAMP(k) do { if (tile_it < 2) st[tile_it * 4 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long g_stamps[256 * 16];
+#define VTC_STAMP(k) do { if (tile_it < 2) stamp_t[tile_it * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VTC_STAMP(k) do { } while (0)
 #endif
@@ -70,6 +70,11 @@ struct Tile256 {
   static constexpr int OFF_A1 = OFF_B1 + B1_ROWS * 128;
   static constexpr int BUF = OFF_A1 + kHalfBytes;
   static constexpr int SMEM = 2 * BUF;
+  // 16-bit outputs leave through LDS (see the epilogue): two regions of GPR row groups x 16 rows x both wave rows
+  static constexpr int GPR = BN == 192 ? 2 : 1;
+  static constexpr int PITCH = BN * 2;
+  static constexpr int REGION = 2 * GPR * 16 * PITCH;
+  static_assert(SMEM + 2 * REGION <= 160 * 1024, "staging + output regions must fit the CU's LDS");
 };
 
 // Tile order: columns are walked in groups of group_n; inside a group tile_n runs fastest, then tile_m.  With the
@@ -88,8 +93,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   constexpr int NJ1 = TC::NJ1;
   static_assert(!(EPI & EPI_RESID), "fp32 residual is not supported here (the encoder keeps a 16-bit residual stream)");
   static_assert(!(EPI & EPI_LNRES) || (BN == 192 && !(EPI & (EPI_F32 | EPI_GELU | EPI_RESID16 | EPI_LNIN))),
-                "EPI_LNRES: 192-wide tiles (16 groups of 48 columns per 768-wide row), split 16-bit output");
-  __shared__ __attribute__((aligned(16))) char smem[TC::SMEM];
+                "EPI_LNRES: 192-wide tiles (16 groups of 48 columns per 768-wide row), 16-bit output");
+  constexpr bool OUT_LDS = !(EPI & (EPI_F32 | EPI_GELU));   // GELU epilogues are VALU-bound: their direct stores drain under it
+  __shared__ __attribute__((aligned(16))) char smem[TC::SMEM + (OUT_LDS ? 2 * TC::REGION : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   bool first_tile = true;
 #ifdef VTC_STAMPS
-  long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long stamp_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int tile_it = 0;
 #endif
 
@@ -369,13 +375,78 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       rowoff[g] = row < p.M ? (unsigned)(row * p.ldc) : OOB;
       rowidx[g] = row < p.M ? (unsigned)row : OOB;
     }
+    // 16-bit outputs leave through LDS.  Straight from the C^T accumulators a store instruction writes 16 rows x 64 B (or
+    // 32 B): partial 128-B lines, which a CU retires at ~10 B/clk however many CUs store (tools/store_bench: 9.8 k cycles
+    // per 256 x 192 tile, against 2.7 k for the same bytes as whole lines).  So the four waves of a wave row put GPR row
+    // groups (16 rows x BN columns each) into an LDS region, swizzled so that neither side has bank conflicts, and after one
+    // barrier read them back as whole rows: every store instruction then writes eight full lines.  Two regions alternate,
+    // so there is one barrier per round (the lgkmcnt(0) in front of it also retires the reads of the round before last).
+    // All arithmetic (bias, GELU, LayerNorm terms, packing) is done first for the whole tile, so that its independent
+    // chains interleave freely; the rounds behind it only move data.
+    constexpr int GPR = TC::GPR, PITCH = TC::PITCH, CPR = BN / 8, NRD = GPR * 16 * CPR / 256;
+    [[maybe_unused]] auto eswz = [](int chunk, int l) {   // 16-B chunk of row l -> its place in the LDS row
+      return BN == 192 ? ((chunk & ~7) | ((chunk ^ (l >> 1)) & 7)) : ((chunk & ~15) | ((chunk ^ l) & 15));
+    };
+    [[maybe_unused]] u32x4 po0[8];                                  // packed outputs of the 8 row groups: B0 columns
+    [[maybe_unused]] u32x4 po1[NJ1 == 2 ? 8 : 4];                   // B1 columns (BN = 192: two row groups per entry)
+    [[maybe_unused]] auto put = [&](int g, u32x4 o0, u32x4 o1) {    // arithmetic first, for all groups; LDS rounds after
+      po0[g] = o0;
+      if constexpr (NJ1 == 2) po1[g] = o1;
+      else { po1[g >> 1][2 * (g & 1)] = o1[0]; po1[g >> 1][2 * (g & 1) + 1] = o1[1]; }
+    };
+    [[maybe_unused]] auto flush_outputs = [&]() {
+      int el_;   // lane id from an opaque source: values derived from it are not kept live across the K loop
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el_));
+      const int fr_ = el_ & 15, fq_ = el_ >> 4;
+      char* const ebase = smem + TC::SMEM + wm * (GPR * 16 * PITCH);
+      char* const wbase = ebase + fr_ * PITCH;
+      const int w0 = eswz(wn * 4 + fq_, fr_) * 16;
+      const int w1 = NJ1 == 2 ? eswz(16 + wn * 4 + fq_, fr_) * 16 : eswz(16 + wn * 2 + (fq_ >> 1), fr_) * 16 + (fq_ & 1) * 8;
+      auto write_round = [&](int rd) {
+#pragma unroll
+        for (int gg = 0; gg < GPR; ++gg) {
+          const int g = rd * GPR + gg;
+          char* r = wbase + (rd & 1) * TC::REGION + gg * 16 * PITCH;
+          *(u32x4*)(r + w0) = po0[g];
+          if constexpr (NJ1 == 2) *(u32x4*)(r + w1) = po1[g];
+          else *(u32x2*)(r + w1) = u32x2{po1[g >> 1][2 * (g & 1)], po1[g >> 1][2 * (g & 1) + 1]};
+        }
+      };
+      write_round(0);
+#pragma unroll
+      for (int rd = 0; rd < 8 / GPR; ++rd) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* rb = ebase + (rd & 1) * TC::REGION;
+        const int g0 = rd * GPR;
+        u32x4 v[NRD];
+        int l[NRD], c[NRD];
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+          const int q = (wn * NRD + k) * 64 + el_;
+          l[k] = q / CPR; c[k] = q - l[k] * CPR;
+          v[k] = *(const u32x4*)(rb + l[k] * PITCH + eswz(c[k], l[k]) * 16);
+        }
+        if (rd + 1 < 8 / GPR) write_round(rd + 1);   // the other region: its readers passed this round's barrier
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+          const int row = tile_m * 256 + (g0 >> 2) * 128 + wm * 64 + (g0 & 3) * 16 + l[k];
+#ifdef VTC_ABL_NOSTORE
+          const unsigned off = OOB;
+#else
+          const unsigned off = row < p.M ? (unsigned)(row * p.ldc + ccol_z + tile_n * BN) * 2u + (unsigned)c[k] * 16u : OOB;
+#endif
+          __builtin_amdgcn_raw_buffer_store_b128(v[k], rc, off, 0, VTC_STORE_AUX);
+        }
+      }
+    };
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rstat = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.ln_stats, 0, (EPI & (EPI_LNIN | EPI_LNRES)) ? (int)((long long)p.M * 8) : 0, 0x00020000);
     if constexpr (EPI & EPI_LNRES) {
-      // ---- residual = LayerNorm(u_h + u_l), output rows split into two 16-bit halves, partial row statistics.
-      // Four passes of two row groups: the residual halves of a pass are all fetched before its first store.
+      // ---- residual = LayerNorm(u) from the 16-bit pre-LN rows and their statistics; partial statistics of the new rows
       const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)p.res_h, 0, (int)((long long)p.M * p.ldc * 2), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rpart = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, (int)((long long)p.M * 128), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rpart =
+          __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, (int)(((long long)15 * p.part_rows + p.M) * 8), 0x00020000);
       float gv0[8], gv1[4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -386,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const float4 t = *(const float4*)(p.res_g + col1);
         gv1[0] = t.x; gv1[1] = t.y; gv1[2] = t.z; gv1[3] = t.w;
       }
-      const unsigned part_col = (unsigned)((tile_n * 4 + wn) * 8);   // byte offset of this wave's (mean, M2) inside a row's 128 B
+      const unsigned part_grp = (unsigned)((tile_n * 4 + wn) * p.part_rows);   // first row of this wave's column group
       // vmcnt counts loads and stores alike and the compiler has to assume they complete out of order, so any wait for a
       // load while a store is pending is a full drain (vmcnt(0)): it then waits for the store acknowledgements of the whole
       // chip's output burst, microseconds per tile (measured: a second pass of loads behind the first pass's stores costs
@@ -405,11 +476,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(h0[g]), "v"(h1[g]), "v"(st[g]));
+      VTC_STAMP(4);
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int mq = g >> 2, i = g & 3;
         const int row = row_of(g);
-        const unsigned ro = row < p.M ? (unsigned)(row * p.ldc) : OOB;
         const float a_r = __uint_as_float(st[g][1]);                 // rstd
         const float b_r = -__uint_as_float(st[g][0]) * a_r;          // -mean * rstd
         float v[12];
@@ -440,10 +511,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const u32x2 pm = {__float_as_uint(mean), __float_as_uint(qd)};
         const u32x4 o0 = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
         const u32x2 o1 = {pack2<F16>(v[8], v[9]), pack2<F16>(v[10], v[11])};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, rc, ro == OOB ? OOB : (ro + (unsigned)col0) * 2u, 0, VTC_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(o1, rc, ro == OOB ? OOB : (ro + (unsigned)col1) * 2u, 0, VTC_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (unsigned)row * 128u + part_col, 0, 0);
+        put(g, o0, u32x4{o1[0], o1[1], 0u, 0u});
+        __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (part_grp + (unsigned)row) * 8u, 0, 0);
       }
+      VTC_STAMP(5);
+      flush_outputs();
     } else {
     [[maybe_unused]] float ln_mu[8], ln_rs[8], cs0[8], cs1[W1];
     if constexpr (EPI & EPI_LNIN) {
@@ -518,9 +590,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
       if constexpr (EPI & EPI_GELU) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v0[k] = gelu_f(v0[k]);
+        for (int k = 0; k < 8; k += 2) gelu2(v0[k], v0[k + 1]);
 #pragma unroll
-        for (int k = 0; k < W1; ++k) v1[k] = gelu_f(v1[k]);
+        for (int k = 0; k < W1; k += 2) gelu2(v1[k], v1[k + 1]);
       }
       if constexpr (EPI & EPI_RESID16) {
 #pragma unroll
@@ -549,16 +621,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
       } else {
         const u32x4 o0 = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v0[4], v0[5]), pack2<F16>(v0[6], v0[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, rc, VTC_OFF_ST(g, col0, 2u), 0, VTC_STORE_AUX);
-        if constexpr (NJ1 == 2) {
-          const u32x4 o1 = {pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3]), pack2<F16>(v1[4], v1[5]), pack2<F16>(v1[6], v1[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o1, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
+        u32x4 o1 = {pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3]), 0u, 0u};
+        if constexpr (NJ1 == 2) { o1[2] = pack2<F16>(v1[4], v1[5]); o1[3] = pack2<F16>(v1[6], v1[7]); }
+        if constexpr (OUT_LDS) {
+          put(g, o0, o1);
         } else {
-          const u32x2 o1 = {pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
-          __builtin_amdgcn_raw_buffer_store_b64(o1, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(o0, rc, VTC_OFF_ST(g, col0, 2u), 0, VTC_STORE_AUX);
+          if constexpr (NJ1 == 2) __builtin_amdgcn_raw_buffer_store_b128(o1, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b64(u32x2{o1[0], o1[1]}, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
         }
       }
     }
+    VTC_STAMP(5);
+    if constexpr (OUT_LDS) flush_outputs();
     }   // !EPI_LNRES
 #undef VTC_OFF_ST
 #undef VTC_OFF_LD
@@ -570,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #undef VTC_KTILE
 #ifdef VTC_STAMPS
   if (tid == 0 && blockIdx.y == 0)
-    for (int k = 0; k < 8; ++k) g_stamps[blockIdx.x * 8 + k] = st[k];
+    for (int k = 0; k < 16; ++k) g_stamps[blockIdx.x * 16 + k] = stamp_t[k];
 #endif
 }
 

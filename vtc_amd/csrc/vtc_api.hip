@@ -298,7 +298,7 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
       q.C = (char*)p.C + r0 * p.ldc * kEsz;
       q.ln_stats = p.ln_stats + r0 * 2;
       if (p.res_h) q.res_h = p.res_h + r0 * p.ldc;
-      if (p.part) q.part = p.part + r0 * 32;
+      if (p.part) q.part = p.part + r0 * 2;   // group-major: the group stride (part_rows) stays that of the whole matrix
       const double fl = 2.0 * q.M * (double)p.N * p.K;
       // (256-wide tiles for FFN1, 6 rounds x 256 against 8 rounds x 192, measured 0.3 % faster per step but its GELU +
       // LayerNorm epilogue spills 11 registers to scratch: not worth a scratch allocation; 192-wide everywhere.)
@@ -426,10 +426,10 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
   };
   auto ln_res_gemm = [&](const h16* A, const h16* W, const float* bias, const float* gamma, int K) {
     GemmParams p = plain(A, W, m->x16, bias, nullptr, M, 768, K);
-    p.ln_stats = m->ln_stats; p.res_h = m->x16; p.res_g = gamma; p.part = m->ln_part;
+    p.ln_stats = m->ln_stats; p.res_h = m->x16; p.res_g = gamma; p.part = m->ln_part; p.part_rows = (M + 15) & ~15;
     gemm_go<F16, 128, EPI_BIAS | EPI_LNRES>(m, p, 1, s);
     LAUNCH(m, PC_LAYERNORM, 0.0, (double)M * 136, s,
-           hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, m->ln_part, m->ln_stats, M));
+           hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, m->ln_part, m->ln_stats, M, (M + 15) & ~15));
   };
   for (int l = 0; l < VTC_N_LAYERS; ++l) {
     const LayerDev& w = m->layer[l];
@@ -627,7 +627,7 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   TRY(dev_alloc(m, &m->tmp32, MT * 768));
   TRY(dev_alloc(m, &m->x16, MT * 768));
   TRY(dev_alloc(m, &m->ln_stats, MT * 2));
-  TRY(dev_alloc(m, &m->ln_part, MT * 32));
+  TRY(dev_alloc(m, &m->ln_part, (MT + 16) * 32));
   TRY(dev_alloc(m, &m->qkv16, MT * 2304));
   TRY(dev_alloc(m, &m->ctx16, MT * 768));
   TRY(dev_alloc(m, &m->ffn16, MT * 3072));
