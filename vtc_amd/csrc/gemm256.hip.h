@@ -94,7 +94,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   static_assert(!(EPI & EPI_RESID), "fp32 residual is not supported here (the encoder keeps a 16-bit residual stream)");
   static_assert(!(EPI & EPI_LNRES) || (BN == 192 && !(EPI & (EPI_F32 | EPI_GELU | EPI_RESID16 | EPI_LNIN))),
                 "EPI_LNRES: 192-wide tiles (16 groups of 48 columns per 768-wide row), 16-bit output");
-  constexpr bool OUT_LDS = !(EPI & (EPI_F32 | EPI_GELU));   // GELU epilogues are VALU-bound: their direct stores drain under it
+#ifndef VTC_EPI_MODE
+#define VTC_EPI_MODE 1   // tools/gemm_bench A/B: 0 = arithmetic first, GELU kernels store directly; 1 = pipelined rounds, GELU
+#endif                   // direct; 2 = pipelined rounds for every 16-bit output
+  constexpr bool OUT_LDS = !(EPI & EPI_F32) && (VTC_EPI_MODE == 2 || !(EPI & EPI_GELU));
   __shared__ __attribute__((aligned(16))) char smem[TC::SMEM + (OUT_LDS ? 2 * TC::REGION : 0)];
 
   const int tid = threadIdx.x;
@@ -381,8 +384,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // groups (16 rows x BN columns each) into an LDS region, swizzled so that neither side has bank conflicts, and after one
     // barrier read them back as whole rows: every store instruction then writes eight full lines.  Two regions alternate,
     // so there is one barrier per round (the lgkmcnt(0) in front of it also retires the reads of the round before last).
-    // All arithmetic (bias, GELU, LayerNorm terms, packing) is done first for the whole tile, so that its independent
-    // chains interleave freely; the rounds behind it only move data.
     constexpr int GPR = TC::GPR, PITCH = TC::PITCH, CPR = BN / 8, NRD = GPR * 16 * CPR / 256;
     [[maybe_unused]] auto eswz = [](int chunk, int l) {   // 16-B chunk of row l -> its place in the LDS row
       return BN == 192 ? ((chunk & ~7) | ((chunk ^ (l >> 1)) & 7)) : ((chunk & ~15) | ((chunk ^ l) & 15));
@@ -394,49 +395,74 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       if constexpr (NJ1 == 2) po1[g] = o1;
       else { po1[g >> 1][2 * (g & 1)] = o1[0]; po1[g >> 1][2 * (g & 1) + 1] = o1[1]; }
     };
-    [[maybe_unused]] auto flush_outputs = [&]() {
-      int el_;   // lane id from an opaque source: values derived from it are not kept live across the K loop
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el_));
+    [[maybe_unused]] int el_ = 0;   // lane id from an opaque source: values derived from it are not kept live across the K loop
+    if constexpr (OUT_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el_));
+    [[maybe_unused]] char* const ebase = smem + TC::SMEM + wm * (GPR * 16 * PITCH);
+    [[maybe_unused]] auto write_round = [&](int rd) {
       const int fr_ = el_ & 15, fq_ = el_ >> 4;
-      char* const ebase = smem + TC::SMEM + wm * (GPR * 16 * PITCH);
-      char* const wbase = ebase + fr_ * PITCH;
+      char* const wbase = ebase + fr_ * PITCH + (rd & 1) * TC::REGION;
       const int w0 = eswz(wn * 4 + fq_, fr_) * 16;
       const int w1 = NJ1 == 2 ? eswz(16 + wn * 4 + fq_, fr_) * 16 : eswz(16 + wn * 2 + (fq_ >> 1), fr_) * 16 + (fq_ & 1) * 8;
-      auto write_round = [&](int rd) {
 #pragma unroll
-        for (int gg = 0; gg < GPR; ++gg) {
-          const int g = rd * GPR + gg;
-          char* r = wbase + (rd & 1) * TC::REGION + gg * 16 * PITCH;
-          *(u32x4*)(r + w0) = po0[g];
-          if constexpr (NJ1 == 2) *(u32x4*)(r + w1) = po1[g];
-          else *(u32x2*)(r + w1) = u32x2{po1[g >> 1][2 * (g & 1)], po1[g >> 1][2 * (g & 1) + 1]};
-        }
-      };
-      write_round(0);
+      for (int gg = 0; gg < GPR; ++gg) {
+        const int g = rd * GPR + gg;
+        char* r = wbase + gg * 16 * PITCH;
+        *(u32x4*)(r + w0) = po0[g];
+        if constexpr (NJ1 == 2) *(u32x4*)(r + w1) = po1[g];
+        else *(u32x2*)(r + w1) = u32x2{po1[g >> 1][2 * (g & 1)], po1[g >> 1][2 * (g & 1) + 1]};
+      }
+    };
+    // one round: wait for everybody's writes of round rd, read it back as whole rows, put the next round's rows into the
+    // other region (its readers have passed this barrier), then store
+    [[maybe_unused]] auto move_round = [&](int rd, bool write_next) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* rb = ebase + (rd & 1) * TC::REGION;
+      const int g0 = rd * GPR;
+      u32x4 v[NRD];
+      int l[NRD], c[NRD];
 #pragma unroll
-      for (int rd = 0; rd < 8 / GPR; ++rd) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const char* rb = ebase + (rd & 1) * TC::REGION;
-        const int g0 = rd * GPR;
-        u32x4 v[NRD];
-        int l[NRD], c[NRD];
+      for (int k = 0; k < NRD; ++k) {
+        const int q = (wn * NRD + k) * 64 + el_;
+        l[k] = q / CPR; c[k] = q - l[k] * CPR;
+        v[k] = *(const u32x4*)(rb + l[k] * PITCH + eswz(c[k], l[k]) * 16);
+      }
+      if (write_next) write_round(rd + 1);
 #pragma unroll
-        for (int k = 0; k < NRD; ++k) {
-          const int q = (wn * NRD + k) * 64 + el_;
-          l[k] = q / CPR; c[k] = q - l[k] * CPR;
-          v[k] = *(const u32x4*)(rb + l[k] * PITCH + eswz(c[k], l[k]) * 16);
-        }
-        if (rd + 1 < 8 / GPR) write_round(rd + 1);   // the other region: its readers passed this round's barrier
-#pragma unroll
-        for (int k = 0; k < NRD; ++k) {
-          const int row = tile_m * 256 + (g0 >> 2) * 128 + wm * 64 + (g0 & 3) * 16 + l[k];
+      for (int k = 0; k < NRD; ++k) {
+        const int row = tile_m * 256 + (g0 >> 2) * 128 + wm * 64 + (g0 & 3) * 16 + l[k];
 #ifdef VTC_ABL_NOSTORE
-          const unsigned off = OOB;
+        const unsigned off = OOB;
 #else
-          const unsigned off = row < p.M ? (unsigned)(row * p.ldc + ccol_z + tile_n * BN) * 2u + (unsigned)c[k] * 16u : OOB;
+        const unsigned off = row < p.M ? (unsigned)(row * p.ldc + ccol_z + tile_n * BN) * 2u + (unsigned)c[k] * 16u : OOB;
 #endif
-          __builtin_amdgcn_raw_buffer_store_b128(v[k], rc, off, 0, VTC_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v[k], rc, off, 0, VTC_STORE_AUX);
+      }
+    };
+    // the tile's row groups through arithmetic (group(g) ends in put(g, ..)) and out: either all arithmetic first, or
+    // round by round with the arithmetic of round r + 1 in front of the barrier of round r, so that the LDS latencies,
+    // the barrier skew and the store issue of a round hide under the next round's VALU work
+    [[maybe_unused]] auto run_rounds = [&](auto&& group) {
+      constexpr int R = 8 / GPR;
+      if constexpr (VTC_EPI_MODE == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) group(g);
+        VTC_STAMP(5);
+        write_round(0);
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) move_round(rd, rd + 1 < R);
+      } else {
+#pragma unroll
+        for (int gg = 0; gg < GPR; ++gg) group(gg);
+        write_round(0);
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+          if (rd + 1 < R) {
+#pragma unroll
+            for (int gg = 0; gg < GPR; ++gg) group((rd + 1) * GPR + gg);
+          }
+          move_round(rd, rd + 1 < R);
         }
       }
     };
@@ -477,8 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(h0[g]), "v"(h1[g]), "v"(st[g]));
       VTC_STAMP(4);
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
+      run_rounds([&](int g) {
         const int mq = g >> 2, i = g & 3;
         const int row = row_of(g);
         const float a_r = __uint_as_float(st[g][1]);                 // rstd
@@ -513,9 +538,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const u32x2 o1 = {pack2<F16>(v[8], v[9]), pack2<F16>(v[10], v[11])};
         put(g, o0, u32x4{o1[0], o1[1], 0u, 0u});
         __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (part_grp + (unsigned)row) * 8u, 0, 0);
-      }
-      VTC_STAMP(5);
-      flush_outputs();
+      });
     } else {
     [[maybe_unused]] float ln_mu[8], ln_rs[8], cs0[8], cs1[W1];
     if constexpr (EPI & EPI_LNIN) {
@@ -563,8 +586,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
       }
     }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    auto group = [&](int g) {
       const int mq = g >> 2, i = g & 3;
       float v0[8], v1[W1];
       if constexpr (EPI & EPI_LNIN) {   // LN(u) W^T + b = rstd * (u W'^T - mean * colsum) + b'
@@ -631,9 +653,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           else __builtin_amdgcn_raw_buffer_store_b64(u32x2{o1[0], o1[1]}, rc, VTC_OFF_ST(g, col1, 2u), 0, VTC_STORE_AUX);
         }
       }
+    };
+    if constexpr (OUT_LDS) {
+      run_rounds(group);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) group(g);
     }
-    VTC_STAMP(5);
-    if constexpr (OUT_LDS) flush_outputs();
     }   // !EPI_LNRES
 #undef VTC_OFF_ST
 #undef VTC_OFF_LD
