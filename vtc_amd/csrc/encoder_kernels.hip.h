@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                                                          const int* __restrict__ valu_flag, h16* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) _Float16 xp[kC0mFrames * 32];   // 16 KiB
   __shared__ float xs[5 * kC0mFrames + 8];
+  __shared__ __attribute__((aligned(16))) char outs[4 * 4096];             // per wave: 16 frames x 128 channels, 16 bit
   const int b = blockIdx.y;
   if (valu_flag[b]) return;   // block-uniform: operand outside the fp16 range, conv0_valu_fallback_kernel does this window
   const int t0 = blockIdx.x * kC0mFrames;
@@ -257,19 +258,24 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  // A fragments: MFMA tile j of 64-channel group q holds channel 16*(i>>2) + 4*j + (i&3) in operand row i
+  // A fragments: MFMA tile j of 64-channel group q holds channel 32*(j>>1) + 8*(i>>2) + 4*(j&1) + (i&3) in operand row i, so
+  // that a lane's outputs are channels 8*fq .. +8 (tiles 0, 1) and 32 + 8*fq .. +8 (tiles 2, 3): each 16-B store instruction
+  // then writes 64 contiguous bytes per frame and the pair one whole 128-B line (16-B pieces with gaps between them are
+  // partial-line writes, which a CU retires at ~10 B/clk: tools/store_bench)
   u16x8 af[2][4];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = wave * 128 + q * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);
+      const int c = wave * 128 + q * 64 + 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
       af[q][j] = *(const u16x8*)(aop + ((long long)b * 512 + c) * 32 + fq * 8);
     }
   __syncthreads();
+  // Outputs leave through a wave-private LDS tile (16 frames x 256 B, 16-B chunks XOR-swizzled by the frame) and are stored
+  // as whole rows: each store instruction writes 4 frames x 256 B = 8 whole lines.
+  char* const ow = outs + wave * 4096;
 #pragma unroll 2
   for (int ft = 0; ft < kC0mFrames / 16; ++ft) {
-    const int t = t0 + ft * 16 + fr;
     const u16x8 bf = *(const u16x8*)(xp + (ft * 16 + fr) * 32 + fq * 8);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -277,19 +283,28 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mfma16<true>(af[q][j], bf, acc);   // rows: channels 16*fq' + 4j + r of the group, cols: frames
+        acc = mfma16<true>(af[q][j], bf, acc);   // rows: channels 32*(j>>1) + 8*fq + 4*(j&1) + r of the group, cols: frames
         float g0 = acc[0], g1 = acc[1], g2 = acc[2], g3 = acc[3];
         gelu2(g0, g1);
         gelu2(g2, g3);
         pk[2 * j] = pack2<true>(g0, g1);
         pk[2 * j + 1] = pack2<true>(g2, g3);
       }
-      if (t < L0) {
-        h16* dst = out + ((long long)b * L0 + t) * 512 + wave * 128 + q * 64 + 16 * fq;
-        *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-      }
+      // chunk (of 16 in the frame's 256 B) = 8 q + fq and 8 q + 4 + fq
+      *(uint4*)(ow + fr * 256 + (((8 * q + fq) ^ fr) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      *(uint4*)(ow + fr * 256 + (((8 * q + 4 + fq) ^ fr) << 4)) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = k * 4 + (lane >> 4), c = lane & 15;
+      const uint4 v = *(const uint4*)(ow + f * 256 + ((c ^ f) << 4));
+      const int t = t0 + ft * 16 + f;
+      if (t < L0) *(uint4*)(out + ((long long)b * L0 + t) * 512 + wave * 128 + c * 8) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
