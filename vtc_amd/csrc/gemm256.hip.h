@@ -19,8 +19,9 @@
 //     phase after the wait + barrier that retired it.
 //   * the MFMAs compute C^T (W fragment as the A operand): a lane then holds ONE output row and, per 16 x 16
 //     tile, 4 consecutive output columns.  W rows are staged into LDS in a permuted order (perm32 below) so
-//     that the two tiles of a 32-column group give a lane 8 consecutive columns: the epilogue needs no LDS
-//     transpose and stores 16 B per lane straight from the accumulators.
+//     that the two tiles of a 32-column group give a lane 8 consecutive columns (16 B).  The GELU kernels and the fp32
+//     output store those straight from the accumulators; the other 16-bit outputs go through two LDS regions behind the
+//     staging buffers and leave as whole rows (see the epilogue: partial 128-B lines are what a CU stores slowly).
 //   * persistent: a block walks tiles b, b+G, b+2G, ...; the NEXT tile's prologue loads are issued before
 //     the current tile's epilogue (registers only), so loads and stores overlap.
 //
