@@ -444,12 +444,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // the tile's row groups through arithmetic (group(g) ends in put(g, ..)) and out: either all arithmetic first, or
     // round by round with the arithmetic of round r + 1 in front of the barrier of round r, so that the LDS latencies,
     // the barrier skew and the store issue of a round hide under the next round's VALU work
-    [[maybe_unused]] auto run_rounds = [&](auto&& group) {
+    // (before_stores() runs once, in front of the first global store: the place for the wait on loads that the first row
+    // groups did not need, see EPI_LNRES)
+    [[maybe_unused]] auto run_rounds = [&](auto&& group, auto&& before_stores) {
       constexpr int R = 8 / GPR;
       if constexpr (VTC_EPI_MODE == 0) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) group(g);
         VTC_STAMP(5);
+        before_stores();
         write_round(0);
 #pragma unroll
         for (int rd = 0; rd < R; ++rd) move_round(rd, rd + 1 < R);
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int gg = 0; gg < GPR; ++gg) group((rd + 1) * GPR + gg);
           }
+          if (rd == 0) before_stores();
           move_round(rd, rd + 1 < R);
         }
       }
@@ -501,8 +505,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         h1[g] = __builtin_amdgcn_raw_buffer_load_b64(rh, ro == OOB ? OOB : (ro + (unsigned)col1) * 2u, 0, 0);
         st[g] = __builtin_amdgcn_raw_buffer_load_b64(rstat, row < p.M ? (unsigned)row * 8u : OOB, 0, 0);
       }
-#pragma unroll
-      for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(h0[g]), "v"(h1[g]), "v"(st[g]));
+      // The first row groups start as soon as THEIR loads are back (loads return in order and nothing else is pending, so
+      // the compiler's waits are counted ones); the rest of the burst arrives under that arithmetic.  The partial statistics
+      // of those groups are held back, because a store in flight would turn every later load wait into a drain.
+      constexpr int kEarly = VTC_EPI_MODE == 0 ? 8 : 2 * GPR;   // groups computed before the first store
+      u32x2 pm_keep[kEarly];
       VTC_STAMP(4);
       run_rounds([&](int g) {
         const int mq = g >> 2, i = g & 3;
@@ -538,7 +545,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const u32x4 o0 = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
         const u32x2 o1 = {pack2<F16>(v[8], v[9]), pack2<F16>(v[10], v[11])};
         put(g, o0, u32x4{o1[0], o1[1], 0u, 0u});
-        __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (part_grp + (unsigned)row) * 8u, 0, 0);
+        if (g < kEarly) pm_keep[g] = pm;
+        else __builtin_amdgcn_raw_buffer_store_b64(pm, rpart, (row >= p.M || fq != 0) ? OOB : (part_grp + (unsigned)row) * 8u, 0, 0);
+      }, [&]() {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) asm volatile("" ::"v"(h0[g]), "v"(h1[g]), "v"(st[g]));   // every load is back: stores may start
+#pragma unroll
+        for (int g = 0; g < kEarly; ++g) {
+          const int row = row_of(g);
+          __builtin_amdgcn_raw_buffer_store_b64(pm_keep[g], rpart, (row >= p.M || fq != 0) ? OOB : (part_grp + (unsigned)row) * 8u, 0, 0);
+        }
       });
     } else {
     [[maybe_unused]] float ln_mu[8], ln_rs[8], cs0[8], cs1[W1];
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
     };
     if constexpr (OUT_LDS) {
-      run_rounds(group);
+      run_rounds(group, []() {});
     } else {
 #pragma unroll
       for (int g = 0; g < 8; ++g) group(g);
