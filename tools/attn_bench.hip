@@ -13,6 +13,7 @@ using namespace vtc;
 
 int main(int argc, char** argv) {
   const int nw = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 499, iters = 20;
+  const int extra_lds = argc > 3 ? atoi(argv[3]) : 0;   // dynamic LDS nobody uses: > 16 KiB leaves one block per CU
   const long long M = (long long)nw * T;
   h16 *qkv, *ctx;
   CK(hipMalloc(&qkv, M * 2304 * 2)); CK(hipMalloc(&ctx, M * 768 * 2));
@@ -24,7 +25,7 @@ int main(int argc, char** argv) {
   }
   const int nkt = (T + 63) / 64, nqb = ((T + 31) / 32 + kAttnWaves - 1) / kAttnWaves;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto go = [&]() { hipLaunchKernelGGL((attention_kernel<true>), dim3(nqb, nw * 12), dim3(512), 0, 0, qkv, ctx, T, nkt); };
+  auto go = [&]() { hipLaunchKernelGGL((attention_kernel<true>), dim3(nqb, nw * 12), dim3(512), extra_lds, 0, qkv, ctx, T, nkt); };
   go(); go(); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < iters; ++i) go();
