@@ -18,6 +18,7 @@ struct Shape { const char* name; int M, N, K; int rows_per_batch; long long row_
 template <int EPI> void run(const Shape& s, GemmParams p, int which, hipStream_t st) {
   if constexpr (EPI & (EPI_LNRES | EPI_LNIN)) {
     if (which == 192) launch_gemm256<true, EPI, 192>(p, 1, st);
+    if constexpr (!(EPI & EPI_LNRES)) { if (which == 256 && p.N % 256 == 0) launch_gemm256<true, EPI, 256>(p, 1, st); }
   } else {
     if (which == 128) launch_gemm<true, 128, EPI>(p, 1, st);
     else if (which == 256) { if (p.N % 256 == 0) launch_gemm256<true, EPI, 256>(p, 1, st); }

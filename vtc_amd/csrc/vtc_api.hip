@@ -300,9 +300,19 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
       if (p.res_h) q.res_h = p.res_h + r0 * p.ldc;
       if (p.part) q.part = p.part + r0 * 2;   // group-major: the group stride (part_rows) stays that of the whole matrix
       const double fl = 2.0 * q.M * (double)p.N * p.K;
-      // (256-wide tiles for FFN1, 6 rounds x 256 against 8 rounds x 192, measured 0.3 % faster per step but its GELU +
-      // LayerNorm epilogue spills 11 registers to scratch: not worth a scratch allocation; 192-wide everywhere.)
-      LAUNCH(m, PC_GEMM, fl, 0.0, s, (launch_gemm256<F16, EPI, 192>(q, 1, s)));
+      // 192-wide tiles unless 256-wide ones need no more rounds x width over the 256 CUs: FFN1 (N = 3072: 6 rounds x 256
+      // against 8 x 192) then runs its K loop with 16 MFMAs in every phase (81 % against 69 % MFMA utilisation in the loop,
+      // 9 % per launch; 2 registers spilled in the epilogue); QKV (N = 2304: 5 x 256 against 6 x 192) stays 192-wide.
+      bool wide = false;
+      if constexpr (!(EPI & EPI_LNRES)) {
+        const long long tm = (q.M + 255) / 256;
+        const long long r192 = (tm * (p.N / 192) + 255) / 256, r256 = (tm * (p.N / 256) + 255) / 256;
+        wide = p.N % 256 == 0 && r256 * 256 <= r192 * 192;
+        static const int force_bn = getenv("VTC_GEMM_BN") ? atoi(getenv("VTC_GEMM_BN")) : 0;
+        if (force_bn == 192) wide = false;
+        if (wide) LAUNCH(m, PC_GEMM, fl, 0.0, s, (launch_gemm256<F16, EPI, 256>(q, 1, s)));
+      }
+      if (!wide) LAUNCH(m, PC_GEMM, fl, 0.0, s, (launch_gemm256<F16, EPI, 192>(q, 1, s)));
     }
     return;
   } else {
