@@ -11,14 +11,30 @@ import collections, csv, json, sys
 
 stats = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(sys.argv[1]))}
 agg = collections.OrderedDict()
+dropped = collections.Counter()
+TIME_LIKE = ("SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
 for path in sys.argv[3:]:
+    per_pass = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        d = agg.setdefault(r["Kernel_Name"], collections.defaultdict(list))
-        d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        per_pass.setdefault(r["Kernel_Name"], collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in per_pass.items():
+        # a kernel's first launch in a process can carry one-off set-up (code object load, scratch allocation): launches whose
+        # duration-like counter is more than 8 x the median of that kernel's launches are left out of every counter of the pass
+        bad = set()
+        for n in TIME_LIKE:
+            v = d.get(n)
+            if v and len(v) >= 4:
+                med = sorted(v)[len(v) // 2]
+                bad |= {i for i, x in enumerate(v) if med > 0 and x > 8.0 * med}
+        dropped[k] += len(bad)
+        tgt = agg.setdefault(k, collections.defaultdict(list))
+        for n, v in d.items():
+            tgt[n] += [x for i, x in enumerate(v) if i not in bad]
 out = []
 for k, d in agg.items():
     c = {n: sum(v) / len(v) for n, v in d.items()}
-    row = {"kernel": k, "launches_profiled": max(len(v) for v in d.values()), "avg_ns": stats.get(k), "per_launch": c}
+    row = {"kernel": k, "launches_profiled": max(len(v) for v in d.values()), "outlier_launches_left_out": dropped[k],
+           "avg_ns": stats.get(k), "per_launch": c}
     g = c.get
     if g("SQ_BUSY_CU_CYCLES"):
         row["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_BUSY_CU_CYCLES"])
