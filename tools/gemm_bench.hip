@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
       {"qkv0   M=31936 N=2304 K=768  (no bias)", 31936, 2304, 768, 31936, 768, 0, 0},
       {"oproj  M=31936 N=768  K=768  (+resid16)  ", 31936, 768, 768, 31936, 768, 0, EPI_BIAS | EPI_RESID16 | EPI_F32},
       {"qkvc   M=31936 N=2304 K=768  (A cache-resident: rows 16 B apart)", 31936, 2304, 768, 31936, 8, 0, EPI_BIAS},
+      {"ffn2c  M=31936 N=768  K=3072 (+resid16, A cache-resident: rows 16 B apart)", 31936, 768, 3072, 31936, 8, 0, EPI_BIAS | EPI_RESID16 | EPI_F32},
       {"oprojL M=31936 N=768  K=768  (LayerNorm residual)", 31936, 768, 768, 31936, 768, 0, EPI_BIAS | EPI_LNRES},
       {"ffn2L  M=31936 N=768  K=3072 (LayerNorm residual)", 31936, 768, 3072, 31936, 3072, 0, EPI_BIAS | EPI_LNRES},
       {"qkvL   M=31936 N=2304 K=768  (LayerNorm in)", 31936, 2304, 768, 31936, 768, 0, EPI_BIAS | EPI_LNIN},
