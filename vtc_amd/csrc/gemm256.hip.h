@@ -181,8 +181,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   f32x4 acc0[2][4][2];    // [mq][i][j]   columns in B0
   f32x4 acc1[2][4][NJ1];  // [mq][i][j]   columns in B1
   u16x8 fa[2][4], fb0[2][2], fb1[2][NJ1];  // [ks][tile]
+#ifdef VTC_ABL_NOREAD   // tools/gemm_bench timing ablation (results are garbage): fragments never read from LDS
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 8; ++e) fa[ks][i][e] = (unsigned short)(0x3c00 + lane + i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) for (int e = 0; e < 8; ++e) fb0[ks][j][e] = (unsigned short)(0x3800 + lane + j);
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) for (int e = 0; e < 8; ++e) fb1[ks][j][e] = (unsigned short)(0x3400 + lane + j);
+  }
+#define VTC_ABL_READ_RETURN return
+#else
+#define VTC_ABL_READ_RETURN
+#endif
+#ifdef VTC_ABL_NOMFMA   // timing ablation: no MFMAs
+#define VTC_ABL_MMA_RETURN return
+#else
+#define VTC_ABL_MMA_RETURN
+#endif
 
   auto read_a = [&](int buf, int off) {
+    VTC_ABL_READ_RETURN;
     const char* base = smem + buf * TC::BUF + off;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -190,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int i = 0; i < 4; ++i) fa[ks][i] = *(const u16x8*)(base + a_row[i] + (((ks * 4 + fq) ^ a_sw[i]) << 4));
   };
   auto read_b0 = [&](int buf) {
+    VTC_ABL_READ_RETURN;
     const char* base = smem + buf * TC::BUF + TC::OFF_B0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -197,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int j = 0; j < 2; ++j) fb0[ks][j] = *(const u16x8*)(base + b0_row[j] + (((ks * 4 + fq) ^ b0_sw[j]) << 4));
   };
   auto read_b1 = [&](int buf) {
+    VTC_ABL_READ_RETURN;
     const char* base = smem + buf * TC::BUF + TC::OFF_B1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -204,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int j = 0; j < NJ1; ++j) fb1[ks][j] = *(const u16x8*)(base + b1_row[j] + (((ks * 4 + fq) ^ b1_sw[j]) << 4));
   };
   auto mma0 = [&](int mq) {
+    VTC_ABL_MMA_RETURN;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -214,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
   auto mma1 = [&](int mq) {
+    VTC_ABL_MMA_RETURN;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
