@@ -195,6 +195,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #else
 #define VTC_ABL_READ_RETURN
 #endif
+#if defined(VTC_ABL_NOREAD) && defined(VTC_ABL_KEEP_W)   // ... but the W fragments are read
+#define VTC_ABL_READ_RETURN_W
+#else
+#define VTC_ABL_READ_RETURN_W VTC_ABL_READ_RETURN
+#endif
+#if defined(VTC_ABL_NOREAD) && defined(VTC_ABL_KEEP_A)   // ... but the A fragments are read
+#define VTC_ABL_READ_RETURN_A
+#else
+#define VTC_ABL_READ_RETURN_A VTC_ABL_READ_RETURN
+#endif
 #ifdef VTC_ABL_NOMFMA   // timing ablation: no MFMAs
 #define VTC_ABL_MMA_RETURN return
 #else
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #endif
 
   auto read_a = [&](int buf, int off) {
-    VTC_ABL_READ_RETURN;
+    VTC_ABL_READ_RETURN_A;
     const char* base = smem + buf * TC::BUF + off;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int i = 0; i < 4; ++i) fa[ks][i] = *(const u16x8*)(base + a_row[i] + (((ks * 4 + fq) ^ a_sw[i]) << 4));
   };
   auto read_b0 = [&](int buf) {
-    VTC_ABL_READ_RETURN;
+    VTC_ABL_READ_RETURN_W;
     const char* base = smem + buf * TC::BUF + TC::OFF_B0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int j = 0; j < 2; ++j) fb0[ks][j] = *(const u16x8*)(base + b0_row[j] + (((ks * 4 + fq) ^ b0_sw[j]) << 4));
   };
   auto read_b1 = [&](int buf) {
-    VTC_ABL_READ_RETURN;
+    VTC_ABL_READ_RETURN_W;
     const char* base = smem + buf * TC::BUF + TC::OFF_B1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
