@@ -127,4 +127,5 @@ def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, famil
 # Oracle logit std of the uncalibrated weights on the calibration clip (synth_audio(40 s, seed 9000), 10 s windows, full
 # windows only); written by tests/golden/make_head_calibration.py, which also commits tests/golden/head_calibration.json.
 HEAD_CALIBRATION: dict = {"stress:0": 0.864546, "stress:1": 2.370401, "stress:2": 0.574449, "stress:3": 2.047762,
-                          "hubert:0": 2.250636, "hubert:1": 2.099057, "hubert:2": 1.722512, "hubert:3": 2.136115}
+                          "hubert:0": 2.250636, "hubert:1": 2.099057, "hubert:2": 1.722512, "hubert:3": 2.136115,
+                          "hubert:4": 2.133864, "hubert:5": 1.794613, "hubert:6": 1.870844, "hubert:7": 2.578898}
