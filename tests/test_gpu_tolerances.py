@@ -58,6 +58,13 @@ def test_c1_600s_north_star_tolerances(seed, chunk):
         assert min(c[table]["oracle_matched"], c[table]["gpu_matched"]) >= bar, (table, c[table])
 
 
+@pytest.mark.parametrize("seed", [4, 5, 6, 7])
+def test_c1_600s_north_star_tolerances_more_weight_seeds(seed):
+    """Four more weight sets of the prescribed family at the bench configuration (10 s windows); both window lengths of all
+    eight seeds are in profiles/r02_parity_report*.json."""
+    test_c1_600s_north_star_tolerances(seed, 10.0)
+
+
 @pytest.mark.parametrize("seed,chunk", [(0, 10.0), (2, 10.0), (2, 4.0)])
 def test_c1_600s_adversarial_weight_family_is_pinned(seed, chunk):
     """The three worst cases of the "stress" family (profiles/r02_parity_report.json has all eight)."""
