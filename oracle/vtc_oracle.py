@@ -113,16 +113,17 @@ def plan_windows(n_samples: int, chunk_duration_s: float) -> WindowPlan:
 
 # --------------------------------------------------------------------------- weights
 def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, family: str = "stress",
-                 calibrated: bool = False) -> dict:
+                 calibrated: bool = False, outlier_scale: float = 1.0) -> dict:
     """Seeded random BabyHuBERT-shaped weights (the real VTC-2.0 checkpoint is absent offline) as torch tensors.
 
     The tensors are INPUT DATA shared with the HIP path, so there is one generator: vtc_amd.synth.make_weights (numpy
-    PCG64, the same tensors on every machine; families "stress" = 1/sqrt(fan_in) scales and "hubert" = the HuBERT-base
-    initialisation of SURVEY.md 8d; calibrated=True applies the committed head scale of tests/golden/head_calibration.json).
+    PCG64, the same tensors on every machine; families "stress" = 1/sqrt(fan_in) scales, "hubert" = the HuBERT-base
+    initialisation of SURVEY.md 8d, "trained" = that plus outlier residual channels and non-unit LayerNorm gains; calibrated=True applies the committed head scale of tests/golden/head_calibration.json).
     Names follow the HF state dict so the same dict can be loaded into transformers.HubertModel for pinning; the
     "hydra" head is one linear unit per label on the last hidden state (UNPINNED topology)."""
     from vtc_amd import synth
-    w = synth.make_weights(seed=seed, n_labels=n_labels, logit_std=logit_std, family=family, calibrated=calibrated)
+    w = synth.make_weights(seed=seed, n_labels=n_labels, logit_std=logit_std, family=family, calibrated=calibrated,
+                           outlier_scale=outlier_scale)
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
 
 
@@ -138,24 +139,32 @@ def _q(x: torch.Tensor, emulate_bf16: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if emulate_bf16 else x
 
 
-def encoder_stages(w: dict, wav: torch.Tensor, emulate_bf16: bool = False) -> dict:
+def encoder_stages(w: dict, wav: torch.Tensor, emulate_bf16: bool = False, ranges: dict | None = None) -> dict:
     """Forward (B, W) fp32 waveforms; returns every stage output (fp32).
 
     emulate_bf16=True rounds every GEMM operand (activations and weights) to bf16 with fp32
     accumulation, which is what the MFMA path does; used to size the error budget on CPU.
+    ranges: if a dict, receives max |value| of every tensor class the HIP path keeps in 16-bit storage between kernels
+    (conv activations, pre-LayerNorm residual rows, q/k/v, attention context, FFN hidden): how close a weight set comes
+    to the fp16 limit of 65,504.
     """
     q = lambda t: _q(t, emulate_bf16)
     out = {}
+
+    def see(name, t):
+        if ranges is not None:
+            ranges[name] = max(ranges.get(name, 0.0), float(t.abs().max()))
+        return t
     x = wav[:, None, :]
     # conv 0 + GroupNorm(512 groups) + GELU   (modeling_hubert.py:154-175); conv0 stays fp32 in HIP too
     x = F.conv1d(x, w["feature_extractor.conv_layers.0.conv.weight"], stride=CONV_STRIDES[0])
     x = F.group_norm(x, 512, w["feature_extractor.conv_layers.0.layer_norm.weight"],
                      w["feature_extractor.conv_layers.0.layer_norm.bias"], eps=1e-5)
-    x = F.gelu(x)
+    x = see("conv_activations", F.gelu(x))
     out["conv0"] = x
     for i in range(1, 7):  # modeling_hubert.py:106-124
         x = F.conv1d(q(x), q(w[f"feature_extractor.conv_layers.{i}.conv.weight"]), stride=CONV_STRIDES[i])
-        x = F.gelu(x)
+        x = see("conv_activations", F.gelu(x))
         out[f"conv{i}"] = x
     x = x.transpose(1, 2)  # (B, T, 512)
     # feature projection (modeling_hubert.py:216-231)
@@ -166,7 +175,7 @@ def encoder_stages(w: dict, wav: torch.Tensor, emulate_bf16: bool = False) -> di
     # positional conv + residual + LN (modeling_hubert.py:83-92, 439-441)
     pc = F.conv1d(q(x.transpose(1, 2)), q(pos_conv_weight(w)), w["encoder.pos_conv_embed.conv.bias"],
                   padding=64, groups=16)[:, :, :-1]
-    x = x + F.gelu(pc).transpose(1, 2)
+    x = see("pre_layernorm_rows", x + F.gelu(pc).transpose(1, 2))
     x = F.layer_norm(x, (768,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], eps=1e-5)
     out["enc_in"] = x
     b, t, _ = x.shape
@@ -176,15 +185,15 @@ def encoder_stages(w: dict, wav: torch.Tensor, emulate_bf16: bool = False) -> di
         qh = F.linear(xq, q(w[p + "attention.q_proj.weight"]), w[p + "attention.q_proj.bias"]) * 0.125
         kh = F.linear(xq, q(w[p + "attention.k_proj.weight"]), w[p + "attention.k_proj.bias"])
         vh = F.linear(xq, q(w[p + "attention.v_proj.weight"]), w[p + "attention.v_proj.bias"])
-        qh, kh, vh = (q(z).view(b, t, 12, 64).transpose(1, 2) for z in (qh, kh, vh))
+        qh, kh, vh = (q(see("qkv", z)).view(b, t, 12, 64).transpose(1, 2) for z in (qh, kh, vh))
         att = torch.softmax(qh @ kh.transpose(2, 3), dim=-1)   # modeling_hubert.py:248-253
-        ctx = (q(att) @ vh).transpose(1, 2).reshape(b, t, 768)
-        x = x + F.linear(q(ctx), q(w[p + "attention.out_proj.weight"]), w[p + "attention.out_proj.bias"])
+        ctx = see("attention_context", (q(att) @ vh).transpose(1, 2).reshape(b, t, 768))
+        x = see("pre_layernorm_rows", x + F.linear(q(ctx), q(w[p + "attention.out_proj.weight"]), w[p + "attention.out_proj.bias"]))
         x = F.layer_norm(x, (768,), w[p + "layer_norm.weight"], w[p + "layer_norm.bias"], eps=1e-5)
-        h = F.gelu(F.linear(q(x), q(w[p + "feed_forward.intermediate_dense.weight"]),
-                            w[p + "feed_forward.intermediate_dense.bias"]))
-        x = x + F.linear(q(h), q(w[p + "feed_forward.output_dense.weight"]),
-                         w[p + "feed_forward.output_dense.bias"])
+        h = see("ffn_hidden", F.gelu(F.linear(q(x), q(w[p + "feed_forward.intermediate_dense.weight"]),
+                                              w[p + "feed_forward.intermediate_dense.bias"])))
+        x = see("pre_layernorm_rows", x + F.linear(q(h), q(w[p + "feed_forward.output_dense.weight"]),
+                                                   w[p + "feed_forward.output_dense.bias"]))
         x = F.layer_norm(x, (768,), w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"], eps=1e-5)
         out[f"layer{l}"] = x
     out["logits"] = F.linear(x, w["head.weight"], w["head.bias"])   # head stays fp32
@@ -192,13 +201,13 @@ def encoder_stages(w: dict, wav: torch.Tensor, emulate_bf16: bool = False) -> di
 
 
 @torch.no_grad()
-def encoder_logits(w: dict, wav: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
-    return encoder_stages(w, wav, emulate_bf16)["logits"]
+def encoder_logits(w: dict, wav: torch.Tensor, emulate_bf16: bool = False, ranges: dict | None = None) -> torch.Tensor:
+    return encoder_stages(w, wav, emulate_bf16, ranges)["logits"]
 
 
 @torch.no_grad()
 def apply_model_on_waveform(w: dict, wav: np.ndarray, chunk_duration_s: float, batch_size: int = 8,
-                            emulate_bf16: bool = False) -> torch.Tensor:
+                            emulate_bf16: bool = False, ranges: dict | None = None) -> torch.Tensor:
     """Oracle of segma.inference.apply_model_on_audio (call site src/pipeline/vtc.py:236-243)
     after decoding: tile -> batched forward -> concatenate frames -> (n_frames, n_labels)."""
     wav = np.asarray(wav, dtype=np.float32)
@@ -211,7 +220,7 @@ def apply_model_on_waveform(w: dict, wav: np.ndarray, chunk_duration_s: float, b
         batch = np.zeros((len(idx), plan.window), dtype=np.float32)
         for r, i in enumerate(idx):
             batch[r, : plan.valid[i]] = wav[plan.starts[i]: plan.starts[i] + plan.valid[i]]
-        lg = encoder_logits(w, torch.from_numpy(batch), emulate_bf16)
+        lg = encoder_logits(w, torch.from_numpy(batch), emulate_bf16, ranges)
         for r, i in enumerate(idx):
             rows.append(lg[r, : plan.keep[i]])
     return torch.cat(rows, dim=0)

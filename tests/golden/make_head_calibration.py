@@ -3,7 +3,7 @@
 
 For every (family, seed) the fp32 CPU oracle runs the uncalibrated weights of vtc_amd.synth.make_weights on the calibration
 clip (synth_audio(40 s, seed 9000), 10 s windows, full windows only) and records the std of the logits pooled over
-frames and labels.  make_weights(..., calibrated=True) multiplies head.weight and head.bias by 2 / that std, so the oracle's
+frames and labels (family "trained": after removing the per-label mean, which is recorded too).  make_weights(..., calibrated=True) multiplies head.weight and head.bias by 2 / that std, so the oracle's
 logit std on the clip is exactly 2.  Writes tests/golden/head_calibration.json and prints the HEAD_CALIBRATION dict to paste into
 vtc_amd/synth.py (the product package cannot import from tests/ or oracle/).
 
@@ -32,17 +32,26 @@ def main():
     x = torch.from_numpy(np.stack([audio[s: s + plan.window] for s in plan.starts[:n]]))
     table, doc = {}, {"clip": {"seconds": CLIP_SECONDS, "seed": CLIP_SEED, "chunk_duration_s": CHUNK, "windows": n},
                       "target_logit_std": 2.0, "entries": {}}
-    for family in ("stress", "hubert"):
+    center = {}
+    for family in ("stress", "hubert", "trained"):
         for seed in range(8 if family == "hubert" else 4):   # the prescribed family on eight seeds
             w = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_weights(seed=seed, family=family).items()}
             with torch.no_grad():
                 logits = O.encoder_logits(w, x).reshape(-1, 4)
+            entry = {}
+            if family == "trained":      # a trained head is balanced: remove the per-label mean first (head.bias -= mean)
+                mean = logits.mean(dim=0)
+                logits = logits - mean
+                center[f"{family}:{seed}"] = [round(float(v), 6) for v in mean]
+                entry["label_mean_logit"] = center[f"{family}:{seed}"]
             raw = float(logits.std())
             table[f"{family}:{seed}"] = round(raw, 6)
-            doc["entries"][f"{family}:{seed}"] = {"uncalibrated_logit_std": round(raw, 6), "head_scale": round(2.0 / raw, 6)}
-            print(family, seed, doc["entries"][f"{family}:{seed}"], flush=True)
+            entry.update({"uncalibrated_logit_std": round(raw, 6), "head_scale": round(2.0 / raw, 6)})
+            doc["entries"][f"{family}:{seed}"] = entry
+            print(family, seed, entry, flush=True)
     (Path(__file__).resolve().parent / "head_calibration.json").write_text(json.dumps(doc, indent=1) + "\n")
     print("HEAD_CALIBRATION: dict = " + json.dumps(table))
+    print("HEAD_CENTER: dict = " + json.dumps(center))
 
 
 if __name__ == "__main__":

@@ -1,8 +1,13 @@
 """BASELINE.json north_star tolerances on the C1 workload (configs[0]: one 10-minute 16 kHz recording), HIP path against
 the fp32 CPU oracle, asserted unconditionally:
 
-    per-frame logits within 2e-2 abs;  per-frame label agreement >= 99.9 %;  segment onset / offset within one 20 ms frame
-    (fraction of segments with both boundaries within one frame, on vtc_raw and on the collar-merged vtc_merged table).
+    per-frame logits within 2e-2 abs;  per-frame label agreement >= 99.9 %;  segment onset / offset within one 20 ms frame.
+
+The boundary criterion is asserted in its exact form (oracle/parity_metrics.py::attribute): every frame-label on which the two
+masks differ has an oracle logit within 2e-2 of the threshold, and every segment of either side, in vtc_raw and in the
+collar-merged vtc_merged table, that has no partner within one frame contains such a frame-label in the range that determines
+it (+-1 frame; +-17 frames = the 0.3 s collar for the merged table).  In other words the two outputs are identical except
+where the oracle's own decision is inside the logit tolerance.  The matched fractions are still reported and floor-checked.
 
 Weights: SURVEY.md 8(d) prescribes "seeded random HuBERT-base init + head scaled so logit std ~ 2"; that is
 synth.make_weights(family="hubert", calibrated=True) (the measured std of every seed is committed in
@@ -31,11 +36,11 @@ MERGED_BOUNDARY = 0.95    # the same on vtc_merged (far fewer, much longer segme
 SECONDS = 600.0
 
 
-def _case(family, seed, chunk, calibrated=True):
+def _case(family, seed, chunk, calibrated=True, ranges=None):
     from vtc_amd.engine import VtcEngine
     w = O.make_weights(seed=seed, family=family, calibrated=calibrated)
     audio = synth.synth_audio(SECONDS, seed=4000 + 10 * seed + int(chunk))
-    ref = O.apply_model_on_waveform(w, audio, chunk, batch_size=8)
+    ref = O.apply_model_on_waveform(w, audio, chunk, batch_size=8, ranges=ranges)
     eng = VtcEngine(w, n_labels=4, chunk_duration_s=chunk, max_batch=16, mfma_dtype="f16", device=0)
     got = eng.infer_waveform(torch.from_numpy(audio).cuda(), batch_size=16)
     torch.cuda.synchronize()
@@ -44,6 +49,17 @@ def _case(family, seed, chunk, calibrated=True):
     c = compare(ref, got.cpu())
     print(json.dumps({"family": family, "seed": seed, "chunk": chunk, **c}))
     return c
+
+
+def _assert_exact_boundary_criterion(c, logit_tol=LOGIT_TOL):
+    a = c["attribution"]
+    assert a["flipped_frame_labels"] == c["flipped_frame_labels"]
+    assert a["max_oracle_abs_logit_at_flips"] <= logit_tol, a["max_oracle_abs_logit_at_flips"]
+    for table in ("raw", "merged"):
+        t = a[table]
+        assert t["unmatched"] == c[table]["oracle_unmatched"] + c[table]["gpu_unmatched"]
+        assert t["unattributed"] == 0, (table, t)         # no boundary moved without a threshold-straddling frame behind it
+        assert t["max_oracle_abs_logit_at_cause"] <= logit_tol, (table, t)
 
 
 @pytest.mark.parametrize("chunk", [4.0, 10.0])
@@ -56,6 +72,7 @@ def test_c1_600s_north_star_tolerances(seed, chunk):
     for table, bar in (("raw", RAW_BOUNDARY), ("merged", MERGED_BOUNDARY)):
         assert c[table]["n_oracle"] > 50, "the recording must produce enough segments for the criterion to mean something"
         assert min(c[table]["oracle_matched"], c[table]["gpu_matched"]) >= bar, (table, c[table])
+    _assert_exact_boundary_criterion(c)
 
 
 @pytest.mark.parametrize("seed", [4, 5, 6, 7])
@@ -71,5 +88,23 @@ def test_c1_600s_adversarial_weight_family_is_pinned(seed, chunk):
     c = _case("stress", seed, chunk)
     assert c["max_abs_logit_err"] <= 3e-2, c["max_abs_logit_err"]
     assert c["frame_label_agreement"] >= 0.998, c["frame_label_agreement"]
+    _assert_exact_boundary_criterion(c, logit_tol=3e-2)
     u = _case("stress", seed, chunk, calibrated=False)       # uncalibrated head (round 1's weights): inside the logit bar
     assert u["max_abs_logit_err"] <= LOGIT_TOL, u["max_abs_logit_err"]
+
+
+@pytest.mark.parametrize("seed,chunk", [(0, 10.0), (1, 10.0), (2, 4.0), (3, 10.0)])
+def test_c1_600s_trained_like_weight_family(seed, chunk):
+    """Weights with the statistics of a trained post-LN encoder (synth.make_weights family "trained": six residual channels
+    at 50-100 x the rest in every LayerNorm output, LayerNorm gains 0.1 ... ~10, non-zero biases, balanced head calibrated
+    to std 2): the north_star bars hold, and the largest value any 16-bit buffer has to hold stays far from fp16's 65,504."""
+    ranges = {}
+    c = _case("trained", seed, chunk, ranges=ranges)
+    print(json.dumps({"family": "trained", "seed": seed, "max_abs_activation": ranges, "fp16_max": 65504.0}))
+    assert 50.0 <= ranges["pre_layernorm_rows"] <= 1000.0          # the outlier channels are really there
+    assert max(ranges.values()) < 65504.0 / 16
+    assert 1.4 <= c["logit_std"] <= 2.6, c["logit_std"]
+    assert c["max_abs_logit_err"] <= LOGIT_TOL, c["max_abs_logit_err"]
+    assert c["frame_label_agreement"] >= AGREEMENT, c["frame_label_agreement"]
+    assert c["raw"]["n_oracle"] > 50
+    _assert_exact_boundary_criterion(c)

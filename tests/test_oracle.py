@@ -146,4 +146,60 @@ def test_head_calibration_fixture_matches_the_generator(golden_dir):
         a = synth.make_weights(seed=int(seed), family=fam)
         b = synth.make_weights(seed=int(seed), family=fam, calibrated=True)
         scale = np.float32(2.0 / e["uncalibrated_logit_std"])
-        assert np.array_equal(b["head.weight"], a["head.weight"] * scale) and np.array_equal(b["head.bias"], a["head.bias"] * scale)
+        bias = a["head.bias"]
+        if "label_mean_logit" in e:            # family "trained": the head is centred before it is scaled
+            assert synth.HEAD_CENTER[key] == e["label_mean_logit"]
+            bias = bias - np.asarray(e["label_mean_logit"], dtype=np.float32)
+        assert np.array_equal(b["head.weight"], a["head.weight"] * scale) and np.array_equal(b["head.bias"], bias * scale)
+
+
+def test_trained_like_family_has_outlier_channels_and_a_balanced_head():
+    """synth.make_weights(family="trained"): six channels of every LayerNorm output sit at 50-100 x the rest, LayerNorm gains
+    are far from 1, and the calibrated head crosses the threshold on every label (oracle, 2 windows of 4 s)."""
+    w = O.make_weights(seed=0, family="trained", calibrated=True)
+    base = O.make_weights(seed=0, family="hubert")
+    assert torch.equal(w["feature_extractor.conv_layers.3.conv.weight"], base["feature_extractor.conv_layers.3.conv.weight"])
+    g = w["encoder.layers.5.final_layer_norm.weight"]
+    assert float(g.max()) > 5.0 and float(g.min()) <= 0.1 + 1e-6
+    audio = synth.synth_audio(8.0, seed=9100)
+    x = torch.from_numpy(np.stack([audio[:64000], audio[64000:128000]]))
+    ranges = {}
+    with torch.no_grad():
+        st = O.encoder_stages(w, x, ranges=ranges)
+    for k in ("enc_in", "layer0", "layer11"):
+        a = st[k].abs().amax(dim=(0, 1))
+        top = torch.sort(a, descending=True).values
+        rms = st[k].pow(2).mean(dim=(0, 1)).sqrt().median()
+        assert 50.0 <= float(top[5]) and float(top[0]) <= 130.0, (k, top[:8])
+        assert float(top[5]) / float(rms) >= 20.0, (k, float(top[5]), float(rms))
+    assert 50.0 <= ranges["pre_layernorm_rows"] < 65504.0 / 16
+    lg = st["logits"].reshape(-1, 4)
+    frac = (lg > 0).float().mean(dim=0)
+    assert float(frac.min()) > 0.1 and float(frac.max()) < 0.9, frac
+
+
+def test_boundary_attribution_accounts_for_every_mismatch():
+    """oracle/parity_metrics.py::attribute on synthetic logit tracks: with small noise every unmatched segment (raw and
+    merged, both directions) is traced to a flipped frame-label in its range; a decode-like difference that is NOT a
+    flip near the threshold (a run cut by hand where the oracle logit is far from 0) shows up as such."""
+    from oracle.parity_metrics import compare
+    g = torch.Generator().manual_seed(0)
+    n = 20000
+    base = torch.cumsum(torch.randn(n, 4, generator=g) * 0.15, 0)
+    base = base - torch.nn.functional.avg_pool1d(base.T[None], 501, 1, 250, count_include_pad=False)[0].T
+    got = base + torch.randn(n, 4, generator=g) * 0.004
+    c = compare(base, got)
+    a = c["attribution"]
+    assert c["flipped_frame_labels"] > 20 and a["raw"]["unmatched"] > 10 and a["merged"]["unmatched"] > 0
+    assert a["raw"]["unattributed"] == 0 and a["merged"]["unattributed"] == 0
+    assert a["max_oracle_abs_logit_at_flips"] <= c["max_abs_logit_err"] <= 0.03
+    # identical logits: nothing to attribute
+    z = compare(base, base.clone())["attribution"]
+    assert z["flipped_frame_labels"] == 0 and z["raw"]["unmatched"] == 0 and z["merged"]["unmatched"] == 0
+    # a gross difference: the flip is attributed, but its oracle logit is far from the threshold and the test bars catch it
+    k = int(torch.argmax(base[:, 0]))
+    bad = base.clone()
+    bad[k, 0] = -1.0
+    b = compare(base, bad)["attribution"]
+    assert b["raw"]["unattributed"] == 0 and b["max_oracle_abs_logit_at_flips"] == pytest.approx(float(base[k, 0]))
+    assert b["max_oracle_abs_logit_at_flips"] > 0.5

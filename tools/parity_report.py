@@ -38,12 +38,15 @@ def main() -> None:
     cases = []
     for family in args.family:
         for seed in args.seeds:
+            if family == "stress" and seed > 3 or family == "trained" and seed > 3:
+                continue            # head calibrations are committed for seeds 0-3 of these families
             w = O.make_weights(seed=seed, family=family, calibrated=not args.uncalibrated)
             for chunk in args.chunks:
                 eng = VtcEngine(w, n_labels=4, chunk_duration_s=chunk, max_batch=16, mfma_dtype=args.dtype, device=0)
                 audio = synth.synth_audio(args.seconds, seed=4000 + 10 * seed + int(chunk))
                 t0 = time.time()
-                ref = O.apply_model_on_waveform(w, audio, chunk, batch_size=8)
+                ranges = {}
+                ref = O.apply_model_on_waveform(w, audio, chunk, batch_size=8, ranges=ranges)
                 t_ref = time.time() - t0
                 got = eng.infer_waveform(torch.from_numpy(audio).to(eng.device), batch_size=16)
                 torch.cuda.synchronize()
@@ -51,6 +54,7 @@ def main() -> None:
                      "chunk_duration_s": chunk, "audio_seconds": len(audio) / 16000.0}
                 c.update(compare(ref, got.cpu()))
                 c["oracle_seconds"] = round(t_ref, 1)
+                c["oracle_max_abs_activation"] = {k: round(v, 2) for k, v in ranges.items()}     # against fp16's 65,504
                 cases.append(c)
                 print(json.dumps(c), flush=True)
                 eng.close()
@@ -62,6 +66,8 @@ def main() -> None:
            "worst_agreement": min(c["frame_label_agreement"] for c in cases),
            "worst_raw_boundary_match": min(min(c["raw"]["oracle_matched"], c["raw"]["gpu_matched"]) for c in cases),
            "worst_merged_boundary_match": min(min(c["merged"]["oracle_matched"], c["merged"]["gpu_matched"]) for c in cases),
+           "unattributed_boundary_mismatches": sum(c["attribution"][t]["unattributed"] for c in cases for t in ("raw", "merged")),
+           "worst_oracle_abs_logit_at_a_flip": max(c["attribution"]["max_oracle_abs_logit_at_flips"] for c in cases),
            "by_family": {f: {"worst_agreement": min(c["frame_label_agreement"] for c in cases if c["family"] == f),
                              "worst_max_abs_logit_err": max(c["max_abs_logit_err"] for c in cases if c["family"] == f)}
                          for f in args.family},

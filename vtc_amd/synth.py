@@ -51,7 +51,7 @@ def synth_audio(duration_s: float, seed: int, dtype=np.float32) -> np.ndarray:
 
 
 def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, family: str = "stress",
-                 calibrated: bool = False) -> dict:
+                 calibrated: bool = False, outlier_scale: float = 1.0) -> dict:
     """Seeded random weights under HF HubertModel state-dict names (+ head.weight / head.bias).
     numpy PCG64 -> identical tensors on every machine.
 
@@ -61,13 +61,20 @@ def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, famil
     family "hubert": the HuBERT-base initialisation SURVEY.md 8(d) prescribes (transformers HubertPreTrainedModel.
         _init_weights with initializer_range 0.02: Linear N(0, 0.02) / bias 0, LayerNorm and GroupNorm 1 / 0, Conv1d
         kaiming-normal, weight-norm g = ||v||).
-    calibrated: scale head.weight and head.bias by the committed factor (HEAD_CALIBRATION, made by tests/golden/make_head_calibration.py
+    family "trained": the "hubert" draws, then statistics a trained post-LN encoder shows and an initialisation does not
+        (_trained_statistics below): six residual channels that sit at +-(50..100) x outlier_scale in every LayerNorm output
+        while the other channels stay at unit scale ("massive activations": near-constant, carried by the LayerNorm biases),
+        LayerNorm / GroupNorm gains far from 1 (the gains behind an outlier-dominated row undo its small rstd: ~6.7 x a
+        log-normal spread; 0.1 on the outlier channels), non-zero biases everywhere, and small read weights on the outlier
+        channels.  This is the case that probes the 16-bit residual rows (precision next to large values, 65,504).
+    calibrated: (family "trained": first subtract the committed per-label mean logit HEAD_CENTER from head.bias, so that every
+        label crosses the threshold; then) scale head.weight and head.bias by the committed factor (HEAD_CALIBRATION, made by tests/golden/make_head_calibration.py
         with the CPU oracle) that brings the oracle's logit std on the calibration clip to `logit_std` = 2 (SURVEY.md 8d:
         "head scaled so logit std ~ 2")."""
-    if family not in ("stress", "hubert"):
+    if family not in ("stress", "hubert", "trained"):
         raise ValueError(f"unknown weight family {family!r}")
     rng = np.random.default_rng(seed)
-    hub = family == "hubert"
+    hub = family in ("hubert", "trained")
 
     def randn(*shape, std=1.0):
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
@@ -114,18 +121,78 @@ def make_weights(seed: int = 0, n_labels: int = 4, logit_std: float = 2.0, famil
         w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"] = affine(768)
     w["head.weight"] = randn(n_labels, 768, std=logit_std * 768 ** -0.5)
     w["head.bias"] = randn(n_labels, std=0.5)
+    if family == "trained":
+        _trained_statistics(w, seed, outlier_scale)
     if calibrated:
         key = f"{family}:{seed}"
+        if outlier_scale != 1.0:
+            key += f":x{outlier_scale:g}"
         if n_labels != 4 or key not in HEAD_CALIBRATION:
             raise ValueError(f"no committed head calibration for {key} with {n_labels} labels")
         scale = np.float32(logit_std / HEAD_CALIBRATION[key])
+        if key in HEAD_CENTER:     # per-label mean logit on the calibration clip, removed before scaling (family "trained")
+            w["head.bias"] = w["head.bias"] - np.asarray(HEAD_CENTER[key], dtype=np.float32)
         w["head.weight"] = w["head.weight"] * scale
         w["head.bias"] = w["head.bias"] * scale
     return w
+
+
+N_OUTLIER_CHANNELS = 6
+
+
+def _trained_statistics(w: dict, seed: int, outlier_scale: float = 1.0) -> None:
+    """Turn a "hubert" draw into the "trained" family in place (its own PCG64 stream, so the base tensors are those of
+    family="hubert" for the same seed).  Fixed point of the construction: every LayerNorm output x has x_S = beta_S =
+    +-(50..100) on the outlier set S and unit-scale values elsewhere; the next pre-LN row u = x + branch then has
+    std_u ~ sqrt(sum beta_S^2 / 768) ~ 6.7, so that LayerNorm's gain on the other channels is std_u x log-normal(0.25) and
+    restores the unit scale, while its gain on S is 0.1 and its bias on S re-creates the outliers."""
+    rng = np.random.default_rng([seed, 0x7A1])
+    f32 = np.float32
+    S = np.sort(rng.choice(768, N_OUTLIER_CHANNELS, replace=False))
+    sign = rng.choice(np.array([-1.0, 1.0]), N_OUTLIER_CHANNELS)
+
+    def spread(n):
+        return np.exp(rng.standard_normal(n) * 0.25)
+
+    def outliers():
+        return sign * rng.uniform(50.0, 100.0, N_OUTLIER_CHANNELS) * outlier_scale
+
+    for nm in ("feature_extractor.conv_layers.0.layer_norm", "feature_projection.layer_norm"):
+        n = w[nm + ".weight"].shape[0]
+        w[nm + ".weight"] = spread(n).astype(f32)
+        w[nm + ".bias"] = (rng.standard_normal(n) * 0.1).astype(f32)
+
+    def layer_norm(nm, std_in):
+        g = std_in * spread(768)
+        b = rng.standard_normal(768) * 0.1
+        a = outliers()
+        g[S], b[S] = 0.1, a
+        w[nm + ".weight"], w[nm + ".bias"] = g.astype(f32), b.astype(f32)
+        m = a.sum() / 768.0
+        return float(np.sqrt((a ** 2).sum() / 768.0 - m * m + 1.0))     # std of the next pre-LN row (unit-scale rest)
+
+    std_u = layer_norm("encoder.layer_norm", 1.0)
+    for l in range(12):
+        p = f"encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            w[p + f"attention.{nm}.weight"][:, S] *= f32(0.2)
+        w[p + "feed_forward.intermediate_dense.weight"][:, S] *= f32(0.2)
+        for nm, n in (("attention.q_proj", 768), ("attention.k_proj", 768), ("attention.v_proj", 768), ("attention.out_proj", 768),
+                      ("feed_forward.intermediate_dense", 3072), ("feed_forward.output_dense", 768)):
+            w[p + nm + ".bias"] = (rng.standard_normal(n) * 0.05).astype(f32)
+        std_u = layer_norm(p + "layer_norm", std_u)
+        std_u = layer_norm(p + "final_layer_norm", std_u)
+    w["feature_projection.projection.bias"] = (rng.standard_normal(768) * 0.05).astype(f32)
+    w["encoder.pos_conv_embed.conv.bias"] = (rng.standard_normal(768) * 0.05).astype(f32)
+    w["head.weight"][:, S] *= f32(0.01 / outlier_scale)
 
 
 # Oracle logit std of the uncalibrated weights on the calibration clip (synth_audio(40 s, seed 9000), 10 s windows, full
 # windows only); written by tests/golden/make_head_calibration.py, which also commits tests/golden/head_calibration.json.
 HEAD_CALIBRATION: dict = {"stress:0": 0.864546, "stress:1": 2.370401, "stress:2": 0.574449, "stress:3": 2.047762,
                           "hubert:0": 2.250636, "hubert:1": 2.099057, "hubert:2": 1.722512, "hubert:3": 2.136115,
-                          "hubert:4": 2.133864, "hubert:5": 1.794613, "hubert:6": 1.870844, "hubert:7": 2.578898}
+                          "hubert:4": 2.133864, "hubert:5": 1.794613, "hubert:6": 1.870844, "hubert:7": 2.578898,
+                          "trained:0": 2.250929, "trained:1": 2.000487, "trained:2": 2.357368, "trained:3": 2.190693}
+# family "trained": per-label mean logit of the uncalibrated weights on that clip (same script)
+HEAD_CENTER: dict = {"trained:0": [7.796665, -2.117744, -3.57752, 0.319455], "trained:1": [-3.903499, 6.581756, -2.683167, 2.39855],
+                     "trained:2": [-20.389849, -10.928957, 9.099744, 4.988534], "trained:3": [1.127458, -1.794585, 3.962687, 1.665586]}
