@@ -105,6 +105,30 @@ def end_to_end_cli(n_files: int, chunk_s: float, batch: int) -> dict:
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def end_to_end_node(n_workers: int, files_per_worker: int, chunk_s: float, batch: int, devices: str = "") -> dict:
+    """The N > 1 form of end_to_end_cli: tools/e2e_node_bench.py starts vtc_amd.launcher with one CLI worker per GPU on a
+    bounded manifest (n_workers x files_per_worker files of 600 s in /dev/shm) and reports the node's file-loop rate.
+    The resident-input `value` scales linearly by construction (independent ranks); this leg is where host decode, PCIe
+    and parquet of N workers share one host.  Runs as a child of rank 0 after every rank has closed its engine.  Never fatal."""
+    import subprocess
+    try:
+        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "e2e_node_bench.py")
+        cmd = [sys.executable, tool, "--workers", str(n_workers), "--files-per-worker", str(files_per_worker), "--chunk", str(chunk_s),
+               "--batch", str(batch)]
+        if devices:
+            cmd += ["--devices", devices]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"value": None, "error": (r.stdout + r.stderr)[-400:]}
+        d = json.loads(lines[-1])
+        keep = ("value", "unit", "workers", "files", "file_seconds", "audio_hours", "file_loop_span_s", "per_worker_steady_state",
+                "with_startup_and_model_construction", "launcher_wall_s", "host_cpus", "what")
+        return {k: d[k] for k in keep}
+    except Exception as e:
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def spawn_ranks(n: int, argv: list[str]) -> int:
     """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), forward
     their output, and return the worst exit status.  Runs before any GPU call: the parent only waits."""
@@ -173,6 +197,8 @@ def main() -> None:
     ap.add_argument("--cpu-windows", type=int, default=120, help="windows of the bounded CPU-oracle sample (~15 s on 16 cores)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end CLI run (files -> parquet) at N=1")
     ap.add_argument("--e2e-files", type=int, default=120, help="600 s PCM16 files of the end-to-end sample (20 audio-hours)")
+    ap.add_argument("--e2e-files-per-worker", type=int, default=480,
+                    help="N > 1: 600 s files per CLI worker of the node-level end-to-end leg (80 audio-hours per worker)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--profile-every", type=int, default=10,
                     help="steps of the timed region whose launches are bracketed by HIP events: every n-th (two event "
@@ -279,6 +305,14 @@ def main() -> None:
         elapsed = float(t.item())
         dist.barrier()
 
+    if use_dist and world > 1 and not args.no_e2e:
+        # the node-level CLI leg below starts one fresh worker process per GPU: give the GPUs back first, on every rank
+        eng.close()
+        del arenas, logits, logits2
+        torch.cuda.empty_cache()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()      # together, before rank 0 goes on alone (CPU baseline / end-to-end legs)
     if rank == 0:
         hours_per_step = args.batch * step / 16000.0 / 3600.0
         value = world * args.steps * hours_per_step / elapsed
@@ -316,9 +350,11 @@ def main() -> None:
         if not args.no_e2e and world == 1:
             eng.close()
             out["end_to_end_cli"] = end_to_end_cli(args.e2e_files, args.chunk, args.batch)
+        elif not args.no_e2e:
+            ndev = max(torch.cuda.device_count(), 1)
+            devs = ",".join(str(i % ndev) for i in range(world)) if rehearse else ""
+            out["end_to_end_cli"] = end_to_end_node(world, args.e2e_files_per_worker, args.chunk, args.batch, devs)
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -126,7 +126,7 @@ int vtc_threshold_mask(vtc_model* m, const float* logits /*[dev]*/, int64_t n_fr
  *     enqueues four kernels on `stream` and performs no hipMalloc / hipFree / host allocation.
  * Limits: n_frames <= VTC_STATIC_DECODE_MAX_FRAMES (larger inputs are rejected with VTC_ERR_CAPACITY; use vtc_decode).
  * result[0] receives the number of intervals found (if it exceeds `cap` only the first `cap` were written; -1 if the run
- * lists were inconsistent), result_summary = {max logit (NaN if a logit is non-finite, as vtc_decode_files), mean sigmoid}.
+ * lists were inconsistent: out_start / out_end / out_label are then left untouched, whatever they held before the call), result_summary = {max logit (NaN if a logit is non-finite, as vtc_decode_files), mean sigmoid}.
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two models) race;
  * nothing has to be cleared between calls (every word a call reads it has written itself). */
 #define VTC_STATIC_DECODE_MAX_FRAMES 262144   /* 87 min of audio at 20 ms per frame */

@@ -282,6 +282,25 @@ def test_large_batch_outputs_over_2gib(weights):
     eng.close()
 
 
+def test_row_chunked_layernorm_gemms_equal_the_unchunked_ones(weights, monkeypatch):
+    """The LayerNorm-input / LayerNorm-residual GEMMs cut outputs over 2 GiB into row chunks and move every per-row array
+    (row statistics, residual rows, partial statistics) with the chunk; that only triggers above ~349 k rows.  The test hook
+    VTC_GEMM_ROWS_MAX forces chunks of 512 / 1280 rows on a small batch: logits must equal the unchunked run bit for bit
+    (M = 24 x 49 = 1176 rows: 3 chunks with a ragged last one, and 1 + a ragged one)."""
+    eng = _engine(weights, 1.0, 24)
+    wav = torch.from_numpy(synth.synth_audio(24.5, seed=31)).cuda()
+    monkeypatch.delenv("VTC_GEMM_ROWS_MAX", raising=False)
+    whole = eng.infer_waveform(wav, batch_size=24).clone()
+    torch.cuda.synchronize()
+    for rows in ("512", "1280", "256"):
+        monkeypatch.setenv("VTC_GEMM_ROWS_MAX", rows)
+        cut = eng.infer_waveform(wav, batch_size=24)
+        torch.cuda.synchronize()
+        assert torch.equal(cut, whole), rows
+    monkeypatch.delenv("VTC_GEMM_ROWS_MAX")
+    eng.close()
+
+
 def test_bf16_mode_error_is_measured_and_bounded(weights):
     """bf16 MFMA operands cannot meet the 2e-2 bar on this model (DESIGN.md 'Precision'); the mode stays
     selectable and its error is pinned here so a regression shows."""

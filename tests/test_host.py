@@ -373,6 +373,24 @@ def test_xlsx_manifest(tmp_path):
     (tmp_path / "old.xls").write_bytes(b"\xd0\xcf\x11\xe0")
     with pytest.raises(RuntimeError, match="xls"):
         utils.load_manifest(tmp_path / "old.xls")
+    # malformed workbooks: every failure is the same RuntimeError naming the file
+    def book(name, sheet_xml, shared_xml=shared, rels_xml=rels):
+        with zipfile.ZipFile(tmp_path / name, "w") as z:
+            z.writestr("xl/workbook.xml", wb)
+            z.writestr("xl/_rels/workbook.xml.rels", rels_xml)
+            z.writestr("xl/sharedStrings.xml", shared_xml)
+            z.writestr("xl/worksheets/sheet1.xml", other)
+            z.writestr("xl/worksheets/sheet2.xml", sheet_xml)
+        return tmp_path / name
+    with pytest.raises(RuntimeError, match="Failed to read Excel"):      # shared-string index out of range
+        utils.load_manifest(book("idx.xlsx", sheet.replace("<v>5</v>", "<v>99</v>")))
+    with pytest.raises(RuntimeError, match="Failed to read Excel"):      # relationship without a Target
+        utils.load_manifest(book("rel.xlsx", sheet, rels_xml=rels.replace(' Target="worksheets/sheet2.xml"', "")))
+    empty = f'<worksheet {ns}><sheetData><row r="1"/><row r="2"/></sheetData></worksheet>'
+    assert utils._read_xlsx(book("empty.xlsx", empty)).num_columns == 0   # rows without cells: an empty table, not a ValueError
+    dup = sheet.replace('<c r="C1" t="s"><v>2</v></c>', '<c r="C1" t="s"><v>0</v></c>')       # header: path, duration, path
+    t2 = utils._read_xlsx(book("dup.xlsx", dup))
+    assert t2.column_names == ["path", "duration", "path_duplicated_0"] and t2.column("path").to_pylist()[0] == "/data/a.wav"
 
 
 def test_batch_size_recommendation():

@@ -53,6 +53,39 @@ def test_static_decode_equals_vtc_decode_twice_in_a_row():
         # against the oracle as well (index work: bit exact)
         want = O.create_intervals(O.apply_thresholds(logits.cpu(), THR))
         assert [(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s[:n], e[:n], lab[:n])] == want
+    # The property the entry point exists for: it neither allocates nor synchronises.  (1) device memory in use is the same
+    # before and after a call; (2) a call made while its stream is being captured into a HIP graph succeeds (an allocation,
+    # a blocking copy or a synchronisation there would fail the capture), and replaying the graph on new logits in the same
+    # buffer gives vtc_decode's answer for those logits.
+    free0 = torch.cuda.mem_get_info()[0]
+    _static(eng, L, small, lo, hi, 4096)
+    assert torch.cuda.mem_get_info()[0] == free0
+    buf = small.clone()
+    cap = 4096
+    gs = torch.full((cap,), -7, dtype=torch.int64, device="cuda")
+    ge = torch.full((cap,), -7, dtype=torch.int64, device="cuda")
+    gl = torch.full((cap,), -7, dtype=torch.int32, device="cuda")
+    gres = torch.full((1,), -9, dtype=torch.int64, device="cuda")
+    gsum = torch.zeros(2, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = L.vtc_decode_static(eng._handle, C.c_void_p(buf.data_ptr()), int(buf.shape[0]), lo.ctypes.data_as(lib._f32p),
+                                 hi.ctypes.data_as(lib._f32p), C.c_void_p(gs.data_ptr()), C.c_void_p(ge.data_ptr()),
+                                 C.c_void_p(gl.data_ptr()), cap, C.c_void_p(gres.data_ptr()), C.c_void_p(gsum.data_ptr()),
+                                 eng._stream())
+        lib.check(rc, eng._handle)
+    for trial in range(2):
+        fresh = torch.from_numpy(rng.standard_normal((3_001, 4)).astype(np.float32)).cuda()
+        buf.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        ws, we, wl, wmax, wmean = eng.decode(fresh, lo, hi)
+        n = int(gres.item())
+        assert n == len(ws) and np.array_equal(gs.cpu().numpy()[:n], ws) and np.array_equal(ge.cpu().numpy()[:n], we)
+        assert np.array_equal(gl.cpu().numpy()[:n], wl) and gsum[0].item() == wmax and gsum[1].item() == wmean
+    del graph
     # room for fewer runs than there are: the count is still reported, only `cap` runs are written
     ws, we, wl, _, _ = eng.decode(small, lo, hi)
     s, e, lab, n, _ = _static(eng, L, small, lo, hi, 10)

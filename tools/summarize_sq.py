@@ -5,7 +5,9 @@ counter per launch, plus derived figures that can be set beside DESIGN.md's in-l
                         of busy CUs; both are summed over the chip)
   wait_frac           = SQ_WAIT_ANY / SQ_WAVE_CYCLES                         (wave-cycles parked on s_waitcnt / barriers)
   lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-  eff_clock_ghz       = GRBM_GUI_ACTIVE / 8 / average kernel time            (MI355X_MICROARCH.md, DVFS give-back)
+  eff_clock_ghz       = GRBM_GUI_ACTIVE / 8 / average kernel time            (MI355X_MICROARCH.md, DVFS give-back); only for
+                        kernels of 50 us and more: GRBM_GUI_ACTIVE also counts the launch's set-up and drain, which for a
+                        short kernel is longer than the kernel (the figure came out at 4-9 "GHz" for them)
 usage: summarize_sq.py KERNEL_STATS.csv OUT.json PASS1.csv [PASS2.csv ...]"""
 import collections, csv, json, sys
 
@@ -43,7 +45,7 @@ for k, d in agg.items():
         row["issue_stall_frac"] = g("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
     if g("SQ_LDS_IDX_ACTIVE"):
         row["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
-    if g("GRBM_GUI_ACTIVE") and stats.get(k):
+    if g("GRBM_GUI_ACTIVE") and stats.get(k) and stats[k] >= 50_000.0:
         row["eff_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / stats[k]
     out.append(row)
 out.sort(key=lambda r: -(r["avg_ns"] or 0) * r["launches_profiled"])

@@ -289,7 +289,11 @@ void gemm_go(vtc_model* m, GemmParams p, int nz, hipStream_t s) {
   if constexpr ((EPI & (EPI_LNIN | EPI_LNRES)) != 0) {
     // LayerNorm-free layer GEMMs exist in the persistent kernel only (any M; N % 192 == 0 and K % 128 == 0 hold for
     // 768 / 2304 / 3072).  Outputs beyond 2 GiB are cut into row chunks; every per-row array moves with the chunk.
-    const long long rows_max = (((1ll << 31) - 1) / ((long long)p.ldc * kEsz)) / 256 * 256;
+    long long rows_max = (((1ll << 31) - 1) / ((long long)p.ldc * kEsz)) / 256 * 256;
+    if (const char* e = getenv("VTC_GEMM_ROWS_MAX")) {   // test hook: force the row-chunk loop on small inputs (multiples of 256)
+      const long long v = atoll(e) / 256 * 256;
+      if (v >= 256 && v < rows_max) rows_max = v;
+    }
     for (long long r0 = 0; r0 < p.M; r0 += rows_max) {
       GemmParams q = p;
       q.M = (int)std::min<long long>(rows_max, p.M - r0);

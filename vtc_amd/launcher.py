@@ -48,6 +48,8 @@ def main(argv=None) -> int:
                                                   "repeating an id puts several workers on one GPU (rehearsals on a small box)")
     ap.add_argument("--cpus_per_worker", type=int, default=0, help="cores per worker (0 = equal share of this process's CPUs)")
     ap.add_argument("--no_affinity", action="store_true", help="do not pin the workers to CPU slices")
+    ap.add_argument("--keep_thread_env", action="store_true",
+                    help="keep OMP_NUM_THREADS / MKL_NUM_THREADS of the calling environment (default: 1 per worker)")
     argv = list(sys.argv[1:] if argv is None else argv)
     rest = []
     if "--" in argv:                     # everything after the first "--" goes to every worker, untouched
@@ -67,6 +69,14 @@ def main(argv=None) -> int:
         return 2
     if not devices:
         devices = [str(i) for i in range(n)]
+    # device ids are positions in what THIS process sees: if the caller already restricted the visible GPUs, map through its list
+    outer = [d.strip() for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()]
+    if outer:
+        try:
+            devices = [outer[int(d)] for d in devices]
+        except (ValueError, IndexError):
+            print(f"--devices {devices} does not fit HIP_VISIBLE_DEVICES={','.join(outer)}", file=sys.stderr)
+            return 2
     procs = []
     slices = worker_cpu_slices(n, args.cpus_per_worker)
     for i in range(n):
@@ -77,9 +87,13 @@ def main(argv=None) -> int:
         budget = thread_budget(len(slices[i]))
         if not args.no_affinity:
             env["VTC_WORKER_CPUS"] = ",".join(str(c) for c in slices[i])
-        env["OMP_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(budget["intra_op"])
+        if not args.keep_thread_env:       # N workers x (all cores) OpenMP threads is never what the caller's setting meant
+            env["OMP_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(budget["intra_op"])
+        else:
+            env.setdefault("OMP_NUM_THREADS", str(budget["intra_op"]))
+            env.setdefault("MKL_NUM_THREADS", str(budget["intra_op"]))
         env.setdefault("VTC_FLAC_THREADS", str(budget["flac_threads"]))
-        if "--prefetch" not in rest:
+        if not any(a == "--prefetch" or a.startswith("--prefetch=") for a in rest):
             extra = ["--prefetch", str(budget["readers"])]
         cmd = ([sys.executable, "-m", "vtc_amd.pipeline.vtc", args.dataset, "--array_id", str(i), "--array_count", str(n)]
                + extra + rest)

@@ -63,15 +63,13 @@ def _tick(name: str, t0: float) -> None:
     with _TIMER_LOCK:
         STAGE_SECONDS[name] += time.perf_counter() - t0
 
-# VRAM -> windows per forward pass; same table as the reference (src/pipeline/resources.py:180-188).
-# Windows of 4 s per forward by device memory.  The reference's table (src/pipeline/resources.py:180-188) was measured on
-# H100 / A40; on MI355X (288 GB) tools/batch_sweep.py (profiles/r02_batch_sweep.json) gives, hot path with inputs resident:
-#   4 s windows: batch 16 / 32 / 64 / 128 / 256 / 512 -> 8.1 / 11.1 / 14.2 / 15.3 / 15.4 / 16.0 audio-h/s (0.8 ... 11.8 GB)
-#  10 s windows: batch 16 / 32 / 64 / 128 / 512       -> 12.0 / 15.2 / 15.8 / 15.6 / 15.8 audio-h/s        (1.1 ... 28.9 GB)
-# i.e. the rate saturates once a forward holds ~25,000 frames (the persistent GEMMs then run >= 2 full rounds of tiles), and
-# the top row of the reference's table (512 windows of 4 s = 102 k frames, 4 % of the card's memory) is also the best point
-# here.  What the reference's table leaves out is the window length: the batch is scaled so that batch x chunk seconds
-# stays what the table means (512 x 4 s), which gives 208 windows at 10 s.
+# Windows of 4 s per forward by device memory: the reference's table (src/pipeline/resources.py:180-188), measured there on
+# H100 / A40.  On MI355X (288 GB) the hot path with inputs resident saturates once a forward holds ~25,000 frames (the
+# persistent GEMMs then run >= 2 full rounds of tiles): at batch 128 x 4 s or 32 x 10 s the rate is within 4 % of the best
+# point, and engine memory is 3-12 GB of the card's 288 (tools/batch_sweep.py; the figures of the current kernels are in the
+# newest profiles/*_batch_sweep.json and in DESIGN.md section 8, not repeated here).  The top row of the reference's table
+# (512 windows of 4 s = 102 k frames) is also the best point here.  What the table leaves out is the window length: the batch
+# is scaled so that batch x chunk seconds stays what the table means (512 x 4 s), which gives 208 windows at 10 s.
 _BATCH_TABLE = [(80, 512), (48, 256), (32, 192), (24, 128), (16, 64), (0, 32)]
 
 
@@ -396,7 +394,10 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
 
         def top_up():
             nonlocal nxt, inflight_bytes
-            while nxt < total and (len(inflight) < depth + 1 or
+            # two recordings in flight whatever their size (the one the GPU works on and the next one); beyond that only
+            # what fits the byte budget, so that a manifest of day-long recordings (3.7 GB of float32 each in HBM, plus the
+            # pinned staging) does not stage `prefetch` of them per worker.  `prefetch` sizes the reader pool, not this.
+            while nxt < total and (len(inflight) < 2 or
                                    (len(inflight) < max_ahead and inflight_bytes + sizes.get(todo[nxt], 0) <= read_budget)):
                 inflight.append((nxt, readers.submit(stage_audio, uid_to_path[todo[nxt]], engine)))
                 inflight_bytes += sizes.get(todo[nxt], 0)
@@ -538,7 +539,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
 
     seg_df, merged_df = write_outputs(final=True)
 
-    wall = time.time() - t0
+    t_end = time.time()
+    wall = t_end - t0
     print(flush=True)
     logger.info("-" * 50)
     logger.info(f"Shard {shard_id} complete")
@@ -553,7 +555,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     log_benchmark(step="vtc", dataset=dataset, n_files=total, wall_seconds=wall, total_audio_seconds=audio_seconds,
                   total_bytes=done_bytes, n_workers=1,
                   extra={"device": torch.cuda.get_device_name(dev_index), "shard_id": shard_id,
-                         "mfma_dtype": model_config.engine.mfma_dtype})
+                         "mfma_dtype": model_config.engine.mfma_dtype, "loop_start_unix": round(t0, 3), "loop_end_unix": round(t_end, 3),
+                         "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()}})
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -571,7 +574,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", default="cuda", choices=["cuda", "cpu", "mps"], help="Only 'cuda' (ROCm) is supported")
     p.add_argument("--array_id", type=int, help="Shard index (SLURM array task ID or launcher rank)")
     p.add_argument("--array_count", type=int, help="Number of shards")
-    p.add_argument("--prefetch", type=int, default=4, help="audio files decoded ahead on host threads")
+    p.add_argument("--prefetch", type=int, default=4,
+                   help="reader threads (container decode + H2D + GPU front-end of the files ahead of the GPU); how many files "
+                        "are staged ahead is bounded by bytes (1 GiB), not by this")
     p.add_argument("--balance", action="store_true",
                    help="shard by file size (longest-processing-time) instead of equal counts; all workers of a run "
                         "must agree on this flag")

@@ -115,6 +115,16 @@ def load_manifest(path: Path) -> pa.Table:
 
 
 def _read_xlsx(path) -> pa.Table:
+    """Any failure to read the workbook is a RuntimeError naming the file, as the reference's (src/utils.py:305-312)."""
+    try:
+        return _read_xlsx_unchecked(path)
+    except RuntimeError:
+        raise
+    except Exception as e:      # malformed parts: missing relationship targets, bad shared-string indices, odd cell refs
+        raise RuntimeError(f"Failed to read Excel file '{path}': {type(e).__name__}: {e}") from e
+
+
+def _read_xlsx_unchecked(path) -> pa.Table:
     """First worksheet of an .xlsx workbook as a table (reference: pl.read_excel, src/utils.py:305-312; openpyxl is not
     needed: the container is a zip of XML parts).  First row = header; shared, inline and formula-cached strings, numbers and
     booleans; empty cells become nulls.  A column whose cells are all numbers stays numeric, anything else is text."""
@@ -171,10 +181,15 @@ def _read_xlsx(path) -> pa.Table:
                 val = int(f) if f.is_integer() and "." not in v.text and "e" not in v.text.lower() else f
             cells[j] = val
         rows.append(cells)
-    if not rows:
+    if not rows or not any(rows):          # no rows, or rows without a single cell
         return pa.table({})
     width = max(max(r) for r in rows if r) + 1
     header = [str(rows[0].get(j)) if rows[0].get(j) is not None else f"column_{j + 1}" for j in range(width)]
+    seen = {}
+    for j, name in enumerate(header):      # duplicate header names get a suffix (polars: "name_duplicated_N") instead of
+        if name in seen:                   # silently collapsing into one column
+            header[j] = f"{name}_duplicated_{seen[name]}"
+        seen[name] = seen.get(name, -1) + 1
     cols = {}
     for j, name in enumerate(header):
         vals = [r.get(j) for r in rows[1:]]
