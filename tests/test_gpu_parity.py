@@ -8,6 +8,7 @@ integer/index work (tiling, stitching, threshold decode) bit-exact.
 
 import json
 import math
+from pathlib import Path
 
 import numpy as np
 import pyarrow.parquet as pq
@@ -1004,6 +1005,63 @@ def test_cli_skewed_manifest_mixed_lengths(weights, tmp_path, monkeypatch):
             assert row[key] == ref_row[key], (uid, key)
     assert n_err >= 2
     eng.close()
+
+
+def test_cli_bundled_staging_equals_per_file_staging(tmp_path, monkeypatch):
+    """Runs of short files are staged as bundles (one pinned buffer, one H2D copy, one front-end launch per bundle:
+    pipeline/vtc.py::stage_bundle).  With files that cannot join a bundle in the middle of the run (44.1 kHz stereo WAV,
+    FLAC, float32 WAV, a file shorter than the receptive field, a missing file) all three tables must equal those of the
+    same manifest staged file by file (VTC_NO_BUNDLE=1), and a batch of 4 windows forces bundles to be cut short."""
+    from scipy.io import wavfile
+    from oracle import flac_codec as FL
+    from vtc_amd.audio import write_wav
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    rng = np.random.default_rng(77)
+    names = []
+    for k in range(70):
+        d = float(np.exp(rng.uniform(np.log(0.5), np.log(20.0))))
+        x = synth.synth_audio(d, seed=1200 + k)
+        p = tmp_path / "audio" / f"b{k:02d}.wav"
+        if k == 9:       # 44.1 kHz stereo
+            up = np.interp(np.arange(int(d * 44100)) / 44100.0, np.arange(len(x)) / 16000.0, x).astype(np.float32)
+            wavfile.write(p, 44100, np.clip(np.round(np.stack([up, 0.3 * up], axis=1) * 32768), -32768, 32767).astype(np.int16))
+        elif k == 21:    # FLAC
+            p = p.with_suffix(".flac")
+            p.write_bytes(FL.encode(np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int64), 16000))
+        elif k == 33:    # float32 WAV
+            wavfile.write(p, 16000, x.astype(np.float32))
+        elif k == 40:    # shorter than the receptive field
+            write_wav(p, x[:399])
+        elif k == 41:    # exactly the receptive field: one frame
+            write_wav(p, x[:400])
+        else:
+            write_wav(p, x)
+        names.append(str(p))
+    names.insert(50, str(tmp_path / "audio" / "missing.wav"))
+    for ds in ("bun", "one"):
+        (tmp_path / "manifests" / f"{ds}.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    staged = []
+    real = cli.stage_bundle
+    monkeypatch.setattr(cli, "stage_bundle", lambda paths, eng: (staged.append(len(paths)), real(paths, eng))[1])
+    cli.main("bun", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=16, prefetch=3)
+    assert len(staged) >= 5 and max(staged) >= 4 and sum(staged) >= 60          # bundles really formed
+    monkeypatch.setenv("VTC_NO_BUNDLE", "1")
+    n_before = len(staged)
+    cli.main("one", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=16, prefetch=3)
+    assert len(staged) == n_before
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        a = pq.read_table(tmp_path / "output" / "bun" / kind / "shard_0.parquet")
+        b = pq.read_table(tmp_path / "output" / "one" / kind / "shard_0.parquet")
+        assert a.num_rows == b.num_rows and a.num_rows > 0
+        assert json.dumps(a.to_pylist(), sort_keys=True) == json.dumps(b.to_pylist(), sort_keys=True), kind
+    meta = pq.read_table(tmp_path / "output" / "bun" / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert [r["uid"] for r in meta] == [Path(n).stem for n in names]
+    errs = {r["uid"]: r["error"] for r in meta if r["error"]}
+    assert set(errs) == {"b40", "missing"} and "too short" in errs["b40"]
 
 
 def pa_buf(b):

@@ -36,48 +36,74 @@ def to_float32(data: np.ndarray) -> np.ndarray:
     return out
 
 
+def _wav_layout(f):
+    """Header of a RIFF/WAVE file open at position 0: (dtype, channels, sample_rate, data offset, frames) for the two
+    formats the GPU front-end takes as they are (PCM16, float32), None for anything else."""
+    import struct
+
+    head = f.read(12)
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        return None
+    fmt = None
+    while True:
+        hdr = f.read(8)
+        if len(hdr) < 8:
+            return None
+        cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+        if cid == b"fmt ":
+            body = f.read(size + (size & 1))
+            if size < 16:
+                return None
+            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and size >= 40:                       # WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the tag
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            if fmt is None:
+                return None
+            tag, ch, sr, bits = fmt
+            dtype = np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else None
+            if dtype is None or ch < 1:
+                return None
+            offset = f.tell()
+            avail = os.fstat(f.fileno()).st_size - offset
+            nbytes = min(size, avail) if size not in (0, 0xFFFFFFFF) else avail
+            return dtype, ch, int(sr), offset, nbytes // (ch * np.dtype(dtype).itemsize)
+        else:
+            f.seek(size + (size & 1), 1)
+
+
 def _fast_wav(path: Path):
     """Minimal RIFF/WAVE reader for the two formats the GPU front-end takes as they are (PCM16, float32): one header
     parse and one read (small files) or a memory map (large ones).  Returns None for anything else - scipy handles it."""
-    import struct
-
     with open(path, "rb") as f:
-        head = f.read(12)
-        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        lay = _wav_layout(f)
+        if lay is None:
             return None
-        fmt = None
-        while True:
-            hdr = f.read(8)
-            if len(hdr) < 8:
-                return None
-            cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
-            if cid == b"fmt ":
-                body = f.read(size + (size & 1))
-                if size < 16:
-                    return None
-                tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
-                if tag == 0xFFFE and size >= 40:                       # WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the tag
-                    tag = struct.unpack("<H", body[24:26])[0]
-                fmt = (tag, ch, sr, bits)
-            elif cid == b"data":
-                if fmt is None:
-                    return None
-                tag, ch, sr, bits = fmt
-                dtype = np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else None
-                if dtype is None or ch < 1:
-                    return None
-                offset = f.tell()
-                avail = os.fstat(f.fileno()).st_size - offset
-                nbytes = min(size, avail) if size not in (0, 0xFFFFFFFF) else avail
-                frame = ch * np.dtype(dtype).itemsize
-                n = nbytes // frame
-                if n * frame >= (8 << 20):
-                    data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(n * ch,))
-                else:
-                    data = np.fromfile(f, dtype=dtype, count=n * ch)
-                return (data.reshape(n, ch) if ch > 1 else data), int(sr)
-            else:
-                f.seek(size + (size & 1), 1)
+        dtype, ch, sr, offset, n = lay
+        if n * ch * np.dtype(dtype).itemsize >= (8 << 20):
+            data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(n * ch,))
+        else:
+            data = np.fromfile(f, dtype=dtype, count=n * ch)
+        return (data.reshape(n, ch) if ch > 1 else data), sr
+
+
+def read_plain_wav_into(path, dst: np.ndarray, pos: int):
+    """Bundle staging of short files (pipeline/vtc.py): if `path` is a mono 16 kHz PCM16 WAV whose samples fit dst[pos:],
+    read them straight into that int16 array (pinned staging memory) and return their count; None for any other file
+    (other formats, rates, channel counts, or no room), which the caller then stages on its own."""
+    if Path(path).suffix.lower() not in (".wav", ".wave"):
+        return None
+    with open(path, "rb", buffering=0) as f:
+        lay = _wav_layout(f)
+        if lay is None:
+            return None
+        dtype, ch, sr, offset, n = lay
+        if dtype is not np.int16 or ch != 1 or sr != SAMPLE_RATE or pos + n > dst.shape[0]:
+            return None
+        f.seek(offset)
+        got = f.readinto(memoryview(dst[pos:pos + n]).cast("B")) if n else 0
+        return got // 2
 
 
 FLAC_THREADS = max(1, int(os.environ.get("VTC_FLAC_THREADS", "4")))      # threads per stream of 32 MB or more

@@ -177,8 +177,17 @@ class VtcEngine:
             raise ValueError("no waveforms")
         for w in wavs:
             self._check_wav(w)
-        arena = wavs[0] if len(wavs) == 1 else torch.cat(wavs)
         n = np.asarray([int(w.numel()) for w in wavs], dtype=np.int64)
+        if len(wavs) == 1:
+            arena = wavs[0]
+        else:
+            # recordings staged as one bundle are consecutive views of one device array: use it as the arena, no copy
+            ptr = np.asarray([w.data_ptr() for w in wavs], dtype=np.int64)
+            store = wavs[0].untyped_storage().data_ptr()
+            if bool(np.all(ptr[1:] == ptr[:-1] + 4 * n[:-1])) and all(w.untyped_storage().data_ptr() == store for w in wavs):
+                arena = torch.as_strided(wavs[0], (int(n.sum()),), (1,), wavs[0].storage_offset())
+            else:
+                arena = torch.cat(wavs)
         off = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int64)
         rows = int(sum(frames_for_samples(int(k)) for k in n))
         logits = torch.empty((max(rows, 1), self.n_labels), dtype=torch.float32, device=self.device)

@@ -38,7 +38,7 @@ import pyarrow.compute as pc
 import pyarrow.parquet as pq
 import torch
 
-from ..audio import read_pcm
+from ..audio import read_pcm, read_plain_wav_into
 from ..core.intervals import intervals_to_columns
 from ..core.metadata import vtc_error_row, vtc_meta_row_columns
 from ..engine import RF_SIZE
@@ -55,7 +55,10 @@ logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s", date
 logger = logging.getLogger("vtc")
 
 _TLS = threading.local()
-STAGE_SECONDS = {"read": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0, "gpu_launch": 0.0, "gpu_collect": 0.0, "finish": 0.0}   # summed wall time per stage (logged at the end)
+# summed wall time per stage (logged at the end).  read = read_file + read_stage (pin + H2D + front-end enqueue) + read_sync
+# summed over the reader threads; gpu_run = gpu_launch + gpu_collect + the decode launch; write = parquet flushes
+STAGE_SECONDS = {"read": 0.0, "read_file": 0.0, "read_stage": 0.0, "read_sync": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0,
+                 "gpu_launch": 0.0, "gpu_collect": 0.0, "finish": 0.0, "write": 0.0}
 _TIMER_LOCK = threading.Lock()
 
 
@@ -122,6 +125,8 @@ def stage_audio(path, engine) -> torch.Tensor:
     H2D and front-end of file i+1 overlap the forward of file i.  Returns only after the waveform is ready."""
     t0 = time.perf_counter()
     pcm, sr = read_pcm(path)
+    _tick("read_file", t0)
+    t1 = time.perf_counter()
     device = engine.device
     copy_stream = getattr(_TLS, "stream", None)
     if copy_stream is None:
@@ -133,11 +138,67 @@ def stage_audio(path, engine) -> torch.Tensor:
         host = torch.from_numpy(pcm)                  # small file, already in memory: a pageable copy is cheaper than pinning
     with torch.cuda.stream(copy_stream):
         wav = engine.prepare_audio(host.to(device, non_blocking=True), sr)
+    _tick("read_stage", t1)
+    t2 = time.perf_counter()
     copy_stream.synchronize()
+    _tick("read_sync", t2)
     _tick("read", t0)
     if wav.numel() < RF_SIZE:
         raise ValueError(f"audio too short: {wav.numel()} samples < receptive field {RF_SIZE}")
     return wav
+
+
+BUNDLE_FILE_BYTES = 4 << 20        # files up to this size (~2 min of 16 kHz PCM16) are staged in bundles
+BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (int16 samples of one bundle)
+BUNDLE_FILES = 256
+
+
+def stage_bundle(paths, engine) -> list:
+    """Reader-thread stage for a run of short files (thousands of 1-30 s recordings: the per-file cost of stage_audio --
+    a pinned allocation, an H2D copy, a front-end launch and a stream synchronisation each -- is then what bounds the run,
+    not the GPU).  Mono 16 kHz PCM16 WAVs are read back to back into this thread's pinned buffer and cross PCIe in ONE
+    copy with ONE front-end launch (int16 -> float32 is per sample, so the concatenation converts as its parts would);
+    the waveforms returned are views of that one device array.  Any other file in the run (another container, rate or
+    channel count) goes through stage_audio on its own.  Returns one waveform or one exception per path, in order."""
+    t0 = time.perf_counter()
+    host = getattr(_TLS, "bundle_host", None)
+    if host is None:
+        host = _TLS.bundle_host = torch.empty(BUNDLE_BYTES // 2, dtype=torch.int16, pin_memory=True)
+    dst = host.numpy()
+    out, spans, pos = [None] * len(paths), [], 0
+    for k, path in enumerate(paths):
+        try:
+            n = read_plain_wav_into(path, dst, pos)
+        except Exception as e:
+            out[k] = e
+            continue
+        if n is None:
+            continue                      # not a plain file: staged on its own below
+        spans.append((k, pos, n))
+        pos += n
+    _tick("read_file", t0)
+    t1 = time.perf_counter()
+    if pos:
+        copy_stream = getattr(_TLS, "stream", None)
+        if copy_stream is None:
+            copy_stream = _TLS.stream = torch.cuda.Stream(engine.device)
+        with torch.cuda.stream(copy_stream):
+            arena = engine.prepare_audio(host[:pos].to(engine.device, non_blocking=True), 16000)
+        _tick("read_stage", t1)
+        t2 = time.perf_counter()
+        copy_stream.synchronize()         # the pinned buffer is free again and the waveforms are ready
+        _tick("read_sync", t2)
+        for k, a, n in spans:
+            out[k] = (arena[a:a + n] if n >= RF_SIZE else
+                      ValueError(f"audio too short: {n} samples < receptive field {RF_SIZE}"))
+    _tick("read", t0)
+    for k, path in enumerate(paths):
+        if out[k] is None:
+            try:
+                out[k] = stage_audio(path, engine)
+            except Exception as e:
+                out[k] = e
+    return out
 
 
 def gpu_stage(engine, gpu_wav: torch.Tensor, lo, hi, batch_size: int, want_logits: bool):
@@ -243,6 +304,10 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
          array_count: int | None = None, sample=None, prefetch: int = 4, balance: bool = False,
          flush_every: int = 0, flush_seconds: float = 300.0, no_group: bool = False):
     set_seeds(42)
+    # Reader threads, the GPU thread and this thread all run Python between their GIL-free calls (file reads, copies, the
+    # library).  With CPython's default 5 ms switch interval a thread that comes back from such a call waits up to 5 ms for the
+    # GIL: at 3,000 short files per second that convoy was a third of the GPU thread's time.
+    sys.setswitchinterval(float(os.environ.get("VTC_SWITCH_INTERVAL", "0.0005")))
     pin = os.environ.get("VTC_WORKER_CPUS", "")
     if pin:      # the launcher's CPU slice for this worker: before any thread pool starts, so every thread inherits it
         try:
@@ -384,6 +449,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     stop = threading.Event()
     read_budget = 1 << 30          # bytes of files being staged ahead of the GPU (short files are read far ahead to fill batches)
     max_ahead = 256
+    bundle = not no_group and os.environ.get("VTC_NO_BUNDLE") != "1"     # A/B switch: stage every file on its own
 
     def gpu_worker(readers):
         """Pulls staged recordings in manifest order; recordings shorter than a batch are grouped until the batch is
@@ -393,15 +459,32 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         group, group_windows = [], 0
 
         def top_up():
+            """Submit reader tasks in manifest order.  A task is one recording, or a bundle: a run of consecutive short
+            files (stage_bundle) of up to one batch of windows, so that thousands of 1-30 s files cost one reader task,
+            one copy and one front-end launch per forward instead of one each."""
             nonlocal nxt, inflight_bytes
-            # two recordings in flight whatever their size (the one the GPU works on and the next one); beyond that only
+            # two tasks in flight whatever their size (the one the GPU works on and the next one); beyond that only
             # what fits the byte budget, so that a manifest of day-long recordings (3.7 GB of float32 each in HBM, plus the
             # pinned staging) does not stage `prefetch` of them per worker.  `prefetch` sizes the reader pool, not this.
             while nxt < total and (len(inflight) < 2 or
                                    (len(inflight) < max_ahead and inflight_bytes + sizes.get(todo[nxt], 0) <= read_budget)):
-                inflight.append((nxt, readers.submit(stage_audio, uid_to_path[todo[nxt]], engine)))
-                inflight_bytes += sizes.get(todo[nxt], 0)
-                nxt += 1
+                first, nbytes, windows = nxt, 0, 0
+                while (bundle and nxt < total and nxt - first < BUNDLE_FILES and 0 < sizes.get(todo[nxt], 0) <= BUNDLE_FILE_BYTES
+                       and nbytes + sizes[todo[nxt]] <= BUNDLE_BYTES):
+                    w_est = max(1, -(-(sizes[todo[nxt]] // 2 - RF_SIZE + 1) // step))     # as if mono 16 kHz PCM16
+                    if nxt > first and windows + w_est > batch_size:
+                        break
+                    windows += w_est
+                    nbytes += sizes[todo[nxt]]
+                    nxt += 1
+                if nxt - first >= 2:
+                    idx = list(range(first, nxt))
+                    inflight.append((idx, nbytes, readers.submit(stage_bundle, [uid_to_path[todo[i]] for i in idx], engine)))
+                else:
+                    nxt = first + 1
+                    nbytes = sizes.get(todo[first], 0)
+                    inflight.append(([first], nbytes, readers.submit(stage_audio, uid_to_path[todo[first]], engine)))
+                inflight_bytes += nbytes
 
         pending = None     # (items, launched): forward enqueued, decode not collected yet
         serial_gpu = os.environ.get("VTC_SERIAL_GPU_STAGE") == "1"    # diagnostic: collect right after launching (A/B timing)
@@ -460,8 +543,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         try:
             top_up()
             while inflight and not stop.is_set():
-                i, fut = inflight.popleft()
-                inflight_bytes -= sizes.get(todo[i], 0)
+                idx, nbytes, fut = inflight.popleft()
+                inflight_bytes -= nbytes
                 top_up()
                 if not fut.done():
                     run_group()          # the next recording is not staged yet: do not hold a partial batch back
@@ -470,24 +553,28 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     _tick("gpu_run", t_run)
                 t_wait = time.perf_counter()
                 try:
-                    wav = fut.result()
+                    staged = fut.result()
+                    staged = staged if len(idx) > 1 else [staged]
                 except Exception as e:
-                    results[i].set_exception(e)
-                    continue
+                    staged = [e] * len(idx)
                 finally:
                     _tick("gpu_wait", t_wait)
-                n_win = -(-(int(wav.numel()) - RF_SIZE + 1) // step)
-                if no_group or n_win >= batch_size:
-                    run_group()
-                    group, group_windows = [(i, wav)], n_win
-                    run_group()
-                    continue
-                if group and group_windows + n_win > batch_size:
-                    run_group()
-                group.append((i, wav))
-                group_windows += n_win
-                if group_windows >= batch_size:
-                    run_group()
+                for i, wav in zip(idx, staged):
+                    if isinstance(wav, BaseException):
+                        results[i].set_exception(wav)
+                        continue
+                    n_win = -(-(int(wav.numel()) - RF_SIZE + 1) // step)
+                    if no_group or n_win >= batch_size:
+                        run_group()
+                        group, group_windows = [(i, wav)], n_win
+                        run_group()
+                        continue
+                    if group and group_windows + n_win > batch_size:
+                        run_group()
+                    group.append((i, wav))
+                    group_windows += n_win
+                    if group_windows >= batch_size:
+                        run_group()
             run_group()
             drain()
         except BaseException as e:       # never leave the consumer waiting on a future that will not resolve
@@ -496,7 +583,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     f.set_exception(RuntimeError(f"GPU worker stopped: {e}"))
             raise
         finally:
-            for _, f in inflight:
+            for _, _, f in inflight:
                 f.cancel()
             for f in results:
                 if not f.done():
@@ -524,7 +611,9 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 since_flush += 1
                 if i + 1 < total and ((flush_every > 0 and since_flush >= flush_every) or
                                       (flush_seconds > 0 and now - last_flush >= flush_seconds)):
+                    t_w = time.perf_counter()
                     write_outputs(final=False)
+                    _tick("write", t_w)
                     since_flush, last_flush = 0, time.time()
                 if (i + 1) % log_every == 0 or i + 1 == total or now - last_log >= 60:
                     rate = bytes_done / max(now - t0, 1e-9)
@@ -537,7 +626,9 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             stop.set()          # an interrupt here must not leave the worker chewing through the rest of the manifest
         worker.result()
 
+    t_w = time.perf_counter()
     seg_df, merged_df = write_outputs(final=True)
+    _tick("write", t_w)
 
     t_end = time.time()
     wall = t_end - t0
