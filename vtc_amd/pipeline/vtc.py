@@ -131,13 +131,37 @@ def stage_audio(path, engine) -> torch.Tensor:
     copy_stream = getattr(_TLS, "stream", None)
     if copy_stream is None:
         copy_stream = _TLS.stream = torch.cuda.Stream(device)
-    if isinstance(pcm, np.memmap) or pcm.nbytes >= (8 << 20) or not pcm.flags.writeable:
-        host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=True)
-        np.copyto(host.numpy(), pcm)                  # page cache / mmap -> pinned staging, no conversion on the host
+    if pcm.nbytes >= 2 * STAGE_CHUNK_BYTES and pcm.flags.c_contiguous:
+        # long recording (a day-long file is 1.8 GB of PCM16): through two pinned 64 MB buffers of this thread, so that the
+        # page-cache -> pinned copy of piece k+1 runs while piece k crosses PCIe, and pinned memory per reader thread is
+        # 128 MB whatever the file size (pinning a file-sized buffer cost as much as reading it)
+        bufs = getattr(_TLS, "chunk_bufs", None)
+        if bufs is None:
+            bufs = _TLS.chunk_bufs = [torch.empty(STAGE_CHUNK_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        flat = pcm.reshape(-1)
+        tdt = torch.int16 if pcm.dtype == np.int16 else torch.float32
+        per = STAGE_CHUNK_BYTES // flat.dtype.itemsize
+        done = [None, None]
+        with torch.cuda.stream(copy_stream):
+            dev = torch.empty(flat.shape[0], dtype=tdt, device=device)
+            for k, a in enumerate(range(0, flat.shape[0], per)):
+                j, m = k & 1, min(per, flat.shape[0] - a)
+                if done[j] is not None:
+                    done[j].synchronize()              # the copy that last used this buffer has left it
+                view = bufs[j][: m * flat.dtype.itemsize].view(tdt)
+                np.copyto(view.numpy(), flat[a:a + m])
+                dev[a:a + m].copy_(view, non_blocking=True)
+                done[j] = torch.cuda.Event()
+                done[j].record(copy_stream)
+            wav = engine.prepare_audio(dev.view(pcm.shape), sr)
     else:
-        host = torch.from_numpy(pcm)                  # small file, already in memory: a pageable copy is cheaper than pinning
-    with torch.cuda.stream(copy_stream):
-        wav = engine.prepare_audio(host.to(device, non_blocking=True), sr)
+        if isinstance(pcm, np.memmap) or pcm.nbytes >= (8 << 20) or not pcm.flags.writeable:
+            host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=True)
+            np.copyto(host.numpy(), pcm)                  # page cache / mmap -> pinned staging, no conversion on the host
+        else:
+            host = torch.from_numpy(pcm)                  # small file, already in memory: a pageable copy is cheaper than pinning
+        with torch.cuda.stream(copy_stream):
+            wav = engine.prepare_audio(host.to(device, non_blocking=True), sr)
     _tick("read_stage", t1)
     t2 = time.perf_counter()
     copy_stream.synchronize()
@@ -148,6 +172,7 @@ def stage_audio(path, engine) -> torch.Tensor:
     return wav
 
 
+STAGE_CHUNK_BYTES = 64 << 20       # long recordings cross PCIe in pieces of this size (two pinned buffers per reader thread)
 BUNDLE_FILE_BYTES = 4 << 20        # files up to this size (~2 min of 16 kHz PCM16) are staged in bundles
 BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (int16 samples of one bundle)
 BUNDLE_FILES = 256
@@ -447,7 +472,10 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     step = engine.step
     results = [Future() for _ in range(total)]
     stop = threading.Event()
-    read_budget = 1 << 30          # bytes of files being staged ahead of the GPU (short files are read far ahead to fill batches)
+    # bytes of files being staged ahead of the GPU (short files are read far ahead to fill batches; two day-long recordings
+    # of 1.8 GB fit, so the next one is read while the GPU is still on the one before the current).  Host cost: pinned
+    # memory is bounded per reader thread (128 MB + 16 MB), not by this; device cost: ~2-3 x this in float32 waveforms.
+    read_budget = int(float(os.environ.get("VTC_READ_BUDGET_GB", "4")) * (1 << 30))
     max_ahead = 256
     bundle = not no_group and os.environ.get("VTC_NO_BUNDLE") != "1"     # A/B switch: stage every file on its own
 
