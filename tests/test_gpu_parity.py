@@ -304,7 +304,13 @@ def test_row_chunked_layernorm_gemms_equal_the_unchunked_ones(weights, monkeypat
 
 def test_bf16_mode_error_is_measured_and_bounded(weights):
     """bf16 MFMA operands cannot meet the 2e-2 bar on this model (DESIGN.md 'Precision'); the mode stays
-    selectable and its error is pinned here so a regression shows."""
+    selectable and its error is pinned here so a regression shows.  The agreement bar is 0.97 on this 12 s clip of
+    stress-family weights (2,400 frame-labels, one label is 0.0004): round 2 moved it from 0.98 when the layers became
+    LayerNorm-free, and round 3 measured that step on the C1-size recordings with both libraries (profiles/
+    r03_bf16_before_after.json, 120 k frame-labels per case): mean |dlogit| 0.0153-0.0158 before, 0.0155-0.0160 after
+    (+1.4 %), agreement 0.99702-0.99824 before, 0.99692-0.99812 after, max error 0.086-0.118 before, 0.084-0.096 after.
+    bf16's error is set by its 8-bit operand mantissa in the conv and FFN contractions, not by where the residual stream is
+    rounded; on a clip this short the 0.98 / 0.97 difference is a handful of labels."""
     wav = synth.synth_audio(12.0, seed=5)
     ref = O.apply_model_on_waveform(weights, wav, 4.0, batch_size=4)
     eng = _engine(weights, 4.0, 4, "bf16")

@@ -371,7 +371,7 @@ def test_xlsx_manifest(tmp_path):
     with pytest.raises(RuntimeError, match="Failed to read Excel"):
         utils.load_manifest(tmp_path / "bad.xlsx")
     (tmp_path / "old.xls").write_bytes(b"\xd0\xcf\x11\xe0")
-    with pytest.raises(RuntimeError, match="xls"):
+    with pytest.raises(RuntimeError, match="Failed to read Excel"):
         utils.load_manifest(tmp_path / "old.xls")
     # malformed workbooks: every failure is the same RuntimeError naming the file
     def book(name, sheet_xml, shared_xml=shared, rels_xml=rels):
@@ -391,6 +391,119 @@ def test_xlsx_manifest(tmp_path):
     dup = sheet.replace('<c r="C1" t="s"><v>2</v></c>', '<c r="C1" t="s"><v>0</v></c>')       # header: path, duration, path
     t2 = utils._read_xlsx(book("dup.xlsx", dup))
     assert t2.column_names == ["path", "duration", "path_duplicated_0"] and t2.column("path").to_pylist()[0] == "/data/a.wav"
+
+
+def _biff(typ: int, data: bytes) -> bytes:
+    import struct
+    return struct.pack("<HH", typ, len(data)) + data
+
+
+def _xls_workbook_stream() -> bytes:
+    """A BIFF8 workbook stream written by hand from [MS-XLS]: globals (BOF, two BOUNDSHEETs, an SST whose third string is
+    split over a CONTINUE record that switches from 8-bit to 16-bit characters, EOF) and two sheets; the first sheet holds
+    LABELSST, NUMBER, RK (integer, x100 and IEEE forms), MULRK, a FORMULA with a cached string (STRING record) and a
+    FORMULA with a cached number."""
+    import struct
+    def ustr8(t):
+        return struct.pack("<HB", len(t), 0) + t.encode("latin-1")
+    bof_g = _biff(0x0809, struct.pack("<HHHHII", 0x0600, 0x0005, 0x0DBB, 0x07CC, 0, 6))
+    bof_s = _biff(0x0809, struct.pack("<HHHHII", 0x0600, 0x0010, 0x0DBB, 0x07CC, 0, 6))
+    eof = _biff(0x000A, b"")
+    strings = ["path", "duration", "/data/a.wav", "note", "ok", "/data/\u00e9t\u00e9.wav"]
+    # string 2 = "/data/a.wav" is cut after "/data/": the rest arrives in a CONTINUE with a fresh option byte (1 = UTF-16)
+    head = struct.pack("<II", len(strings), len(strings)) + ustr8("path") + ustr8("duration") + struct.pack("<HB", 11, 0) + b"/data/"
+    cont = b"\x01" + "a.wav".encode("utf-16-le") + ustr8("note") + ustr8("ok") \
+        + struct.pack("<HB", len(strings[5]), 1) + strings[5].encode("utf-16-le")
+    sst = _biff(0x00FC, head) + _biff(0x003C, cont)
+    def cell(r, c):
+        return struct.pack("<HHH", r, c, 15)
+    rk_int = lambda v: (v << 2) | 2
+    rk_cents = lambda v: (v << 2) | 3
+    rk_f = lambda x: struct.unpack("<Q", struct.pack("<d", x))[0] >> 32 & 0xFFFFFFFC
+    sheet1 = bof_s
+    sheet1 += _biff(0x00FD, cell(0, 0) + struct.pack("<I", 0)) + _biff(0x00FD, cell(0, 1) + struct.pack("<I", 1))
+    sheet1 += _biff(0x00FD, cell(0, 2) + struct.pack("<I", 3))
+    sheet1 += _biff(0x00FD, cell(1, 0) + struct.pack("<I", 2)) + _biff(0x0203, cell(1, 1) + struct.pack("<d", 12.5))
+    sheet1 += _biff(0x00FD, cell(1, 2) + struct.pack("<I", 4))
+    sheet1 += _biff(0x00FD, cell(2, 0) + struct.pack("<I", 5)) + _biff(0x027E, cell(2, 1) + struct.pack("<I", rk_int(7)))
+    sheet1 += _biff(0x0006, cell(3, 0) + b"\x00\x00\x00\x00\x00\x00\xff\xff" + b"\x00" * 8) \
+        + _biff(0x0207, struct.pack("<HB", 11, 0) + b"/data/f.wav")
+    sheet1 += _biff(0x00BD, struct.pack("<HH", 3, 1) + struct.pack("<HI", 15, rk_cents(1234)) + struct.pack("<HI", 15, rk_f(0.5))
+                    + struct.pack("<H", 2))
+    sheet1 += _biff(0x0006, cell(4, 1) + struct.pack("<d", 3.0) + b"\x00" * 8)
+    sheet1 += eof
+    sheet2 = bof_s + _biff(0x0204, cell(0, 0) + ustr8("nope")) + eof
+    def globals_(off1, off2):
+        bs = lambda off, name: _biff(0x0085, struct.pack("<IBB", off, 0, 0) + struct.pack("<BB", len(name), 0) + name.encode())
+        return bof_g + bs(off1, "files") + bs(off2, "x") + sst + eof
+    n = len(globals_(0, 0))
+    return globals_(n, n + len(sheet1)) + sheet1 + sheet2
+
+
+def _cfb(stream: bytes, mini: bool) -> bytes:
+    """A compound file ([MS-CFB], 512-byte sectors) holding one stream named "Workbook": in regular sectors (padded to the
+    4096-byte cut-off) or, for mini=True, in the mini stream of the root entry."""
+    import struct
+    END, FREE, FATSECT = 0xFFFFFFFE, 0xFFFFFFFF, 0xFFFFFFFD
+    def pad(b, n):
+        return b + b"\x00" * (-len(b) % n)
+    def dirent(name, typ, start, size, child=FREE):
+        nm = name.encode("utf-16-le") + b"\x00\x00"
+        return nm.ljust(64, b"\x00") + struct.pack("<HBB", len(nm), typ, 1) + struct.pack("<III", FREE, FREE, child) \
+            + b"\x00" * 36 + struct.pack("<IQ", start, size)
+    sectors, fat = [], []
+    def add(data):          # append a chain of sectors, return its first sector id
+        data = pad(data, 512)
+        first = len(sectors)
+        k = len(data) // 512
+        for i in range(k):
+            sectors.append(data[i * 512:(i + 1) * 512])
+            fat.append(first + i + 1 if i + 1 < k else END)
+        return first
+    if mini:
+        assert len(stream) < 4096
+        mini_stream = pad(stream, 64)
+        n_mini = len(mini_stream) // 64
+        minifat = [i + 1 for i in range(n_mini - 1)] + [END]
+        minifat_sid = add(struct.pack(f"<{len(minifat)}I", *minifat) + struct.pack("<I", FREE) * (-len(minifat) % 128))
+        root_start = add(mini_stream)
+        directory = dirent("Root Entry", 5, root_start, len(mini_stream), child=1) + dirent("Workbook", 2, 0, len(stream))
+        n_minifat_sec = 1
+    else:
+        body = stream + b"\x00" * max(0, 4096 - len(stream))
+        wb_start = add(body)
+        directory = dirent("Root Entry", 5, END, 0, child=1) + dirent("Workbook", 2, wb_start, len(body))
+        minifat_sid, n_minifat_sec = END, 0
+    dir_sid = add(pad(directory, 512))
+    fat_sid = len(sectors)
+    fat.append(FATSECT)
+    sectors.append(pad(struct.pack(f"<{len(fat)}I", *fat), 512).replace(b"", b"", 0))
+    sectors[-1] = struct.pack(f"<{len(fat)}I", *fat) + struct.pack("<I", FREE) * (128 - len(fat))
+    header = bytes.fromhex("D0CF11E0A1B11AE1") + b"\x00" * 16 + struct.pack("<HHHHH", 0x3E, 3, 0xFFFE, 9, 6) + b"\x00" * 6 \
+        + struct.pack("<IIIIIIIII", 0, 1, dir_sid, 0, 4096, minifat_sid, n_minifat_sec, END, 0) \
+        + struct.pack("<I", fat_sid) + struct.pack("<I", FREE) * 108
+    assert len(header) == 512 and len(fat) <= 128
+    return header + b"".join(sectors)
+
+
+def test_xls_manifest(tmp_path):
+    """Legacy .xls manifests (reference src/utils.py:305-312 reads them through polars -> xlrd).  The workbook is written by
+    hand from [MS-CFB] / [MS-XLS] (no Excel-written file is available offline: the reader is unpinned against real Excel
+    output), once in regular sectors and once in the mini stream."""
+    from vtc_amd import utils
+    stream = _xls_workbook_stream()
+    for mini in (False, True):
+        p = tmp_path / f"m{int(mini)}.xls"
+        p.write_bytes(_cfb(stream, mini))
+        t = utils.load_manifest(p)
+        assert t.column_names == ["path", "duration", "note"]
+        assert utils.manifest_paths(t) == ["/data/a.wav", "/data/\u00e9t\u00e9.wav", "/data/f.wav"]
+        assert t.column("duration").to_pylist() == [12.5, 7, 12.34, 3] and t.column("note").to_pylist() == ["ok", None, "0.5", None]
+    bad = bytearray(_cfb(stream, False))
+    bad[0x30:0x34] = b"\x77\x77\x00\x00"                   # directory start beyond the FAT
+    (tmp_path / "bad.xls").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError, match="Failed to read Excel"):
+        utils.load_manifest(tmp_path / "bad.xls")
 
 
 def test_batch_size_recommendation():

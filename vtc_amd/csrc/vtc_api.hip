@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -588,9 +589,11 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
   TRY(upload_f32(m, &m->pos_b, w->pos_b, 768));
   TRY(upload_f32(m, &m->enc_ln_w, w->enc_ln_w, 768));
   TRY(upload_f32(m, &m->enc_ln_b, w->enc_ln_b, 768));
+  // Host-side packing of the 12 layers (LayerNorm folding with fp64 column sums, 16-bit rounding: 7 M weights per layer) runs
+  // on one thread per layer; the uploads follow in layer order.  Single-threaded this was most of the ~1.1 s a model takes to
+  // construct, which every worker process and every test pays.
   for (int l = 0; l < VTC_N_LAYERS; ++l) {
     const vtc_layer_weights& s = w->layer[l];
-    LayerDev& d = m->layer[l];
     if (!s.q_w || !s.k_w || !s.v_w || !s.q_b || !s.k_b || !s.v_b || !s.o_w || !s.ff1_w || !s.ff2_w)
       return bail(fail(m, VTC_ERR_ARG, "missing weight in layer %d", l));
     if (!s.o_b || !s.ln1_w || !s.ln1_b || !s.ff1_b || !s.ff2_b || !s.ln2_w || !s.ln2_b)
@@ -599,36 +602,57 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
     const float* g_in = l == 0 ? w->enc_ln_w : w->layer[l - 1].ln2_w;
     const float* b_in = l == 0 ? w->enc_ln_b : w->layer[l - 1].ln2_b;
     if (!g_in || !b_in) return bail(fail(m, VTC_ERR_ARG, "missing LayerNorm in front of layer %d", l));
-    // fused QKV [2304][768] behind that LayerNorm; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e)
-    // of the softmax's exp2 form (attention.hip.h) are folded into the query rows
-    const float kQScale = 0.125f * 1.4426950408889634f;
-    std::vector<float> wq((size_t)2304 * 768), bq(2304);
-    memcpy(&wq[0], s.q_w, sizeof(float) * 768 * 768);
-    memcpy(&wq[(size_t)768 * 768], s.k_w, sizeof(float) * 768 * 768);
-    memcpy(&wq[(size_t)1536 * 768], s.v_w, sizeof(float) * 768 * 768);
-    memcpy(&bq[0], s.q_b, sizeof(float) * 768);
-    memcpy(&bq[768], s.k_b, sizeof(float) * 768);
-    memcpy(&bq[1536], s.v_b, sizeof(float) * 768);
-    const FoldedLinear fq = fold_layernorm(wq.data(), bq.data(), 2304, 768, g_in, b_in, f16, kQScale, 768);
-    TRY(upload_h16(m, &d.qkv_w, fq.w));
-    TRY(upload_f32(m, &d.qkv_b, fq.bias.data(), 2304));
-    TRY(upload_f32(m, &d.qkv_s, fq.colsum.data(), 2304));
-    TRY(upload_f32(m, &d.g_in, g_in, 768));
-    // out-proj adds the residual LN_in(u): its beta joins the bias
-    TRY(upload_h16(m, &d.o_w, pack_linear(s.o_w, 768, 768, f16)));
-    std::vector<float> obb(768), f2bb(768);
-    for (int i = 0; i < 768; ++i) { obb[i] = s.o_b[i] + b_in[i]; f2bb[i] = s.ff2_b[i] + s.ln1_b[i]; }
-    TRY(upload_f32(m, &d.o_bb, obb.data(), 768));
+  }
+  struct LayerHost { FoldedLinear fq, f1; std::vector<unsigned short> ow, f2w; std::vector<float> obb, f2bb; };
+  std::vector<LayerHost> host(VTC_N_LAYERS);
+  {
+    std::vector<std::thread> pack;
+    for (int l = 0; l < VTC_N_LAYERS; ++l)
+      pack.emplace_back([&, l]() {
+        const vtc_layer_weights& s = w->layer[l];
+        LayerHost& h = host[l];
+        const float* g_in = l == 0 ? w->enc_ln_w : w->layer[l - 1].ln2_w;
+        const float* b_in = l == 0 ? w->enc_ln_b : w->layer[l - 1].ln2_b;
+        // fused QKV [2304][768] behind that LayerNorm; the 64^-0.5 query scale (HF modeling_hubert.py:287,318) and the log2(e)
+        // of the softmax's exp2 form (attention.hip.h) are folded into the query rows
+        const float kQScale = 0.125f * 1.4426950408889634f;
+        std::vector<float> wq((size_t)2304 * 768), bq(2304);
+        memcpy(&wq[0], s.q_w, sizeof(float) * 768 * 768);
+        memcpy(&wq[(size_t)768 * 768], s.k_w, sizeof(float) * 768 * 768);
+        memcpy(&wq[(size_t)1536 * 768], s.v_w, sizeof(float) * 768 * 768);
+        memcpy(&bq[0], s.q_b, sizeof(float) * 768);
+        memcpy(&bq[768], s.k_b, sizeof(float) * 768);
+        memcpy(&bq[1536], s.v_b, sizeof(float) * 768);
+        h.fq = fold_layernorm(wq.data(), bq.data(), 2304, 768, g_in, b_in, f16, kQScale, 768);
+        h.ow = pack_linear(s.o_w, 768, 768, f16);
+        // out-proj adds the residual LN_in(u): its beta joins the bias
+        h.obb.resize(768); h.f2bb.resize(768);
+        for (int i = 0; i < 768; ++i) { h.obb[i] = s.o_b[i] + b_in[i]; h.f2bb[i] = s.ff2_b[i] + s.ln1_b[i]; }
+        h.f1 = fold_layernorm(s.ff1_w, s.ff1_b, 3072, 768, s.ln1_w, s.ln1_b, f16);
+        h.f2w = pack_linear(s.ff2_w, 768, 3072, f16);
+      });
+    for (auto& t : pack) t.join();
+  }
+  for (int l = 0; l < VTC_N_LAYERS; ++l) {
+    const vtc_layer_weights& s = w->layer[l];
+    LayerDev& d = m->layer[l];
+    const LayerHost& h = host[l];
+    TRY(upload_h16(m, &d.qkv_w, h.fq.w));
+    TRY(upload_f32(m, &d.qkv_b, h.fq.bias.data(), 2304));
+    TRY(upload_f32(m, &d.qkv_s, h.fq.colsum.data(), 2304));
+    TRY(upload_f32(m, &d.g_in, l == 0 ? w->enc_ln_w : w->layer[l - 1].ln2_w, 768));
+    TRY(upload_h16(m, &d.o_w, h.ow));
+    TRY(upload_f32(m, &d.o_bb, h.obb.data(), 768));
     TRY(upload_f32(m, &d.ln1_w, s.ln1_w, 768));
     TRY(upload_f32(m, &d.ln1_b, s.ln1_b, 768));
-    const FoldedLinear f1 = fold_layernorm(s.ff1_w, s.ff1_b, 3072, 768, s.ln1_w, s.ln1_b, f16);
-    TRY(upload_h16(m, &d.ff1_w, f1.w));
-    TRY(upload_f32(m, &d.ff1_b, f1.bias.data(), 3072));
-    TRY(upload_f32(m, &d.ff1_s, f1.colsum.data(), 3072));
-    TRY(upload_h16(m, &d.ff2_w, pack_linear(s.ff2_w, 768, 3072, f16)));
-    TRY(upload_f32(m, &d.ff2_bb, f2bb.data(), 768));
+    TRY(upload_h16(m, &d.ff1_w, h.f1.w));
+    TRY(upload_f32(m, &d.ff1_b, h.f1.bias.data(), 3072));
+    TRY(upload_f32(m, &d.ff1_s, h.f1.colsum.data(), 3072));
+    TRY(upload_h16(m, &d.ff2_w, h.f2w));
+    TRY(upload_f32(m, &d.ff2_bb, h.f2bb.data(), 768));
     TRY(upload_f32(m, &d.ln2_w, s.ln2_w, 768));
     TRY(upload_f32(m, &d.ln2_b, s.ln2_b, 768));
+    host[l] = LayerHost();   // release the layer's host copies as soon as they are on the device
   }
   TRY(upload_f32(m, &m->head_w, w->head_w, (size_t)spec->n_labels * 768));
   TRY(upload_f32(m, &m->head_b, w->head_b, spec->n_labels));

@@ -109,8 +109,7 @@ def load_manifest(path: Path) -> pa.Table:
     if suffix == ".xlsx":
         return _read_xlsx(path)
     if suffix == ".xls":
-        # the reference hands .xls to polars -> xlrd (src/utils.py:305-312); the legacy BIFF container has no reader here
-        raise RuntimeError(f"Failed to read Excel file '{path}': legacy .xls (BIFF) is not supported, save it as .xlsx or .csv")
+        return _read_xls(path)
     raise ValueError(f"Unsupported manifest format '{suffix}'. Supported: {', '.join(MANIFEST_EXTENSIONS)}")
 
 
@@ -181,6 +180,11 @@ def _read_xlsx_unchecked(path) -> pa.Table:
                 val = int(f) if f.is_integer() and "." not in v.text and "e" not in v.text.lower() else f
             cells[j] = val
         rows.append(cells)
+    return _rows_to_table(rows)
+
+
+def _rows_to_table(rows: list) -> pa.Table:
+    """rows: one {column index: value} dict per sheet row, first row = header (shared by the .xlsx and .xls readers)."""
     if not rows or not any(rows):          # no rows, or rows without a single cell
         return pa.table({})
     width = max(max(r) for r in rows if r) + 1
@@ -197,6 +201,201 @@ def _read_xlsx_unchecked(path) -> pa.Table:
             vals = [None if v is None else (v if isinstance(v, str) else str(v)) for v in vals]
         cols[name] = vals
     return pa.table(cols)
+
+
+def _read_xls(path) -> pa.Table:
+    """First worksheet of a legacy .xls workbook (reference: pl.read_excel -> xlrd, src/utils.py:305-312).  Any failure is a
+    RuntimeError naming the file."""
+    try:
+        return _rows_to_table(_xls_rows(Path(path).read_bytes()))
+    except Exception as e:
+        raise RuntimeError(f"Failed to read Excel file '{path}': {type(e).__name__}: {e}") from e
+
+
+def _cfb_stream(blob: bytes, names) -> bytes:
+    """One stream of a Compound File Binary container ([MS-CFB]: 512-byte header, FAT / DIFAT sector chains, 128-byte
+    directory entries, streams under the cut-off size in the mini stream of the root entry)."""
+    import struct
+    if blob[:8] != bytes.fromhex("D0CF11E0A1B11AE1"):
+        raise ValueError("not a compound file (bad signature)")
+    sec_shift, mini_shift = struct.unpack_from("<HH", blob, 0x1E)
+    n_fat, dir_start, _, cutoff, minifat_start, n_minifat, difat_start, n_difat = struct.unpack_from("<IIIIIIII", blob, 0x2C)
+    ssz, msz = 1 << sec_shift, 1 << mini_shift
+    END = 0xFFFFFFFE
+
+    def sector(i):
+        return blob[(i + 1) * ssz:(i + 2) * ssz]
+
+    difat = list(struct.unpack_from("<109I", blob, 0x4C))
+    nxt, hops = difat_start, 0
+    while nxt not in (END, 0xFFFFFFFF) and hops < n_difat + 1:
+        vals = struct.unpack(f"<{ssz // 4}I", sector(nxt))
+        difat += vals[:-1]
+        nxt, hops = vals[-1], hops + 1
+    fat = []
+    for sid in difat[:n_fat]:
+        if sid < 0xFFFFFFFC:
+            fat += struct.unpack(f"<{ssz // 4}I", sector(sid))
+
+    def chain(start, table, limit):
+        out, cur = [], start
+        while cur < 0xFFFFFFFC:
+            if cur >= len(table) or len(out) > limit:
+                raise ValueError("broken sector chain")
+            out.append(cur)
+            cur = table[cur]
+        return out
+
+    directory = b"".join(sector(i) for i in chain(dir_start, fat, len(fat)))
+    entries = []
+    for off in range(0, len(directory) - 127, 128):
+        nlen, typ = struct.unpack_from("<HB", directory, off + 0x40)
+        if typ in (2, 5) and 2 <= nlen <= 64:
+            name = directory[off:off + nlen - 2].decode("utf-16-le", "replace")
+            start, size = struct.unpack_from("<IQ", directory, off + 0x74)
+            entries.append((name, typ, start, size & 0xFFFFFFFF if sec_shift == 9 else size))
+    root = next((e for e in entries if e[1] == 5), None)
+    for want in names:
+        for name, typ, start, size in entries:
+            if typ == 2 and name.lower() == want.lower():
+                if size >= cutoff or root is None:
+                    data = b"".join(sector(i) for i in chain(start, fat, len(fat)))
+                else:      # mini stream: 64-byte sectors inside the root entry's stream, chained by the mini FAT
+                    mini = b"".join(sector(i) for i in chain(root[2], fat, len(fat)))
+                    minifat = []
+                    for sid in chain(minifat_start, fat, len(fat)) if n_minifat else []:
+                        minifat += struct.unpack(f"<{ssz // 4}I", sector(sid))
+                    data = b"".join(mini[i * msz:(i + 1) * msz] for i in chain(start, minifat, len(minifat)))
+                return data[:size]
+    raise ValueError(f"no {' / '.join(names)} stream in the file")
+
+
+def _xls_rows(blob: bytes) -> list:
+    """Cell values of the first worksheet of a BIFF8 workbook stream ([MS-XLS]): SST (shared strings, with CONTINUE records
+    that may switch the character width mid-string), LABELSST, LABEL, NUMBER, RK, MULRK, BOOLERR and FORMULA (+ STRING)
+    records; one {column: value} dict per row.  Text cells come back as str, numbers as int where they are whole."""
+    import struct
+    wb = _cfb_stream(blob, ("Workbook", "Book"))
+
+    def records(pos):
+        while pos + 4 <= len(wb):
+            typ, ln = struct.unpack_from("<HH", wb, pos)
+            yield typ, wb[pos + 4:pos + 4 + ln], pos
+            pos += 4 + ln
+
+    def num(x: float):
+        return int(x) if float(x).is_integer() and abs(x) < 2 ** 53 else float(x)
+
+    def rk(v: int):
+        if v & 2:
+            x = float((v >> 2) - (1 << 30 if v & 0x80000000 else 0))
+        else:
+            x = struct.unpack("<d", struct.pack("<Q", (v & 0xFFFFFFFC) << 32))[0]
+        return num(x / 100.0 if v & 1 else x)
+
+    def ustring(chunks, ci, off, cch_bytes=2):
+        """A unicode string that starts at chunks[ci][off:]; the characters (and only they) may run on into the following
+        CONTINUE chunks, each of which then opens with a fresh option byte.  Returns (text, chunk index, offset)."""
+        buf = chunks[ci]
+        cch = struct.unpack_from("<H" if cch_bytes == 2 else "<B", buf, off)[0]
+        off += cch_bytes
+        flags = buf[off]
+        off += 1
+        n_runs = n_ext = 0
+        if flags & 8:
+            n_runs = struct.unpack_from("<H", buf, off)[0]
+            off += 2
+        if flags & 4:
+            n_ext = struct.unpack_from("<I", buf, off)[0]
+            off += 4
+        wide, text = flags & 1, []
+        while cch:
+            if off >= len(buf):
+                ci += 1
+                buf, off = chunks[ci], 1
+                wide = buf[0] & 1
+            take = min(cch, (len(buf) - off) // (2 if wide else 1))
+            raw = buf[off:off + take * (2 if wide else 1)]
+            text.append(raw.decode("utf-16-le", "replace") if wide else raw.decode("latin-1"))
+            off += len(raw)
+            cch -= take
+        skip = 4 * n_runs + n_ext
+        while skip:
+            if off >= len(buf):
+                ci += 1
+                buf, off = chunks[ci], 0
+            step = min(skip, len(buf) - off)
+            off += step
+            skip -= step
+        return "".join(text), ci, off
+
+    sst, sheets, first = [], [], None
+    recs = list(records(0))
+    if not recs or recs[0][0] != 0x0809 or struct.unpack_from("<H", recs[0][1], 0)[0] != 0x0600:
+        raise ValueError("not a BIFF8 workbook (Excel 97-2003)")
+    i = 0
+    while i < len(recs):
+        typ, data, _ = recs[i]
+        if typ == 0x0085:                                   # BOUNDSHEET: stream offset, visibility, type, name
+            sheets.append((struct.unpack_from("<I", data, 0)[0], data[5]))
+        elif typ == 0x00FC:                                 # SST + its CONTINUE records
+            chunks = [data]
+            while i + 1 < len(recs) and recs[i + 1][0] == 0x003C:
+                i += 1
+                chunks.append(recs[i][1])
+            n_unique = struct.unpack_from("<I", data, 4)[0]
+            ci, off = 0, 8
+            for _ in range(n_unique):
+                if off >= len(chunks[ci]):
+                    ci, off = ci + 1, 0
+                s_, ci, off = ustring(chunks, ci, off)
+                sst.append(s_)
+        elif typ == 0x000A:                                 # EOF of the workbook globals
+            break
+        i += 1
+    worksheets = [off for off, kind in sheets if kind == 0]
+    if not worksheets:
+        raise ValueError("no worksheet in the workbook")
+    cells, pending = {}, None
+    for typ, data, _ in records(worksheets[0]):
+        if typ == 0x000A:
+            break
+        if typ in (0x00FD, 0x0203, 0x027E, 0x0204, 0x0205, 0x0006):
+            r, c = struct.unpack_from("<HH", data, 0)
+        if typ == 0x00FD:
+            cells[(r, c)] = sst[struct.unpack_from("<I", data, 6)[0]]
+        elif typ == 0x0203:
+            cells[(r, c)] = num(struct.unpack_from("<d", data, 6)[0])
+        elif typ == 0x027E:
+            cells[(r, c)] = rk(struct.unpack_from("<I", data, 6)[0])
+        elif typ == 0x00BD:                                 # MULRK: row, first column, (xf, rk)*, last column
+            r, c0 = struct.unpack_from("<HH", data, 0)
+            for k in range((len(data) - 6) // 6):
+                cells[(r, c0 + k)] = rk(struct.unpack_from("<I", data, 4 + 6 * k + 2)[0])
+        elif typ == 0x0204:
+            cells[(r, c)] = ustring([data], 0, 6)[0]
+        elif typ == 0x0205:
+            if data[7] == 0:
+                cells[(r, c)] = bool(data[6])
+        elif typ == 0x0006:                                 # FORMULA: cached result; a string result follows in STRING
+            res = data[6:14]
+            if res[6:8] == b"\xff\xff":
+                if res[0] == 0:
+                    pending = (r, c)
+                elif res[0] == 1:
+                    cells[(r, c)] = bool(res[2])
+            else:
+                cells[(r, c)] = num(struct.unpack("<d", res)[0])
+        elif typ == 0x0207 and pending is not None:
+            cells[pending], pending = ustring([data], 0, 0)[0], None
+    if not cells:
+        return []
+    rows = [dict() for _ in range(max(r for r, _ in cells) + 1)]
+    for (r, c), v in cells.items():
+        rows[r][c] = v
+    while rows and not rows[0]:                             # leading empty rows: the header is the first row with cells
+        rows.pop(0)
+    return rows
 
 
 def manifest_paths(table: pa.Table, column: str = "path") -> list[str]:
