@@ -699,5 +699,9 @@ def test_launcher_builds_one_worker_per_device(monkeypatch):
     calls.clear(); envs.clear()
     assert launcher.main(["ds", "--devices", "0,0", "--no_affinity", "--", "--batch_size", "8", "--prefetch", "3"]) == 0   # two workers on one GPU
     assert [c[1] for c in calls] == ["0", "0"] and calls[1][0][-6:] == ["--array_count", "2", "--batch_size", "8", "--prefetch", "3"]
+    calls.clear(); envs.clear()
+    assert launcher.main(["ds", "--gpus", "2", "--per_gpu", "2", "--no_affinity"]) == 0                                   # 2 GPUs x 2 workers
+    assert [c[1] for c in calls] == ["0", "0", "1", "1"] and [c[0][c[0].index("--array_id") + 1] for c in calls] == ["0", "1", "2", "3"]
+    assert all(c[0][c[0].index("--array_count") + 1] == "4" for c in calls)
     assert "VTC_WORKER_CPUS" not in envs[0] or envs[0].get("VTC_WORKER_CPUS") == os.environ.get("VTC_WORKER_CPUS")
     assert launcher.main(["ds", "--gpus", "3", "--devices", "0,1"]) == 2                       # count mismatch
