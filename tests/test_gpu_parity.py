@@ -614,6 +614,7 @@ def test_cli_durable_progress_and_resume_after_crash(tmp_path, monkeypatch):
     assert flushed == uids[:4]                      # two flushes of two files each survived the kill
     seen = []
     monkeypatch.setattr(cli, "stage_audio", lambda path, eng, _f=cli.stage_audio: (seen.append(path), _f(path, eng))[1])
+    monkeypatch.setattr(cli, "stage_bundle", lambda paths, eng, _f=cli.stage_bundle: (seen.extend(paths), _f(paths, eng))[1])
     cli.main("crash", flush_every=2, **common)
     assert [str(p).rsplit("/", 1)[-1] for p in seen] == ["g4.wav", "g5.wav"]   # only the unfinished files were redone
     for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
