@@ -1,13 +1,15 @@
 // Dev tool: time attention_kernel on the encoder's shape (64 windows x 12 heads, T = 499) and, when built with
 // -DVTC_ATTN_STAMPS, print where a wave's time goes per 64-key tile.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DVTC_ATTN_STAMPS] -I vtc_amd/csrc tools/attn_bench.hip -o tools/attn_bench
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DVTC_ATTN_STAMPS] -I vtc_amd/csrc -I tools tools/attn_bench.hip -o tools/attn_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <vector>
 #include "attention.hip.h"
+#include "attention64.hip.h"
 using namespace vtc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -32,6 +34,28 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
   printf("attention nw=%d T=%d: %.1f us  %.1f TFLOP/s\n", nw, T, ms * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / ms / 1e9);
+  {   // the 64-queries-per-wave kernel on the same input: time, and its context rows against the kernel above
+    std::vector<unsigned short> ref((size_t)M * 768), got((size_t)M * 768);
+    CK(hipMemcpy(ref.data(), ctx, ref.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(ctx, 0, M * 768 * 2));
+    const int nqb64 = ((T + 63) / 64 + kAttn64Waves - 1) / kAttn64Waves;
+    auto go64 = [&]() { hipLaunchKernelGGL((attention64_kernel<true>), dim3(nqb64, nw * 12), dim3(256), extra_lds, 0, qkv, ctx, T, nkt); };
+    go64(); go64(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) go64();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms64; CK(hipEventElapsedTime(&ms64, e0, e1)); ms64 /= iters;
+    CK(hipMemcpy(got.data(), ctx, got.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0; size_t ndiff = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+      _Float16 a, c; memcpy(&a, &ref[i], 2); memcpy(&c, &got[i], 2);
+      const double d = fabs((double)a - (double)c);
+      if (d > worst) worst = d;
+      ndiff += ref[i] != got[i];
+    }
+    printf("attention64 nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n", nw, T,
+           ms64 * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / ms64 / 1e9, ndiff, ref.size(), worst);
+  }
 #ifdef VTC_ATTN_STAMPS
   std::vector<long long> h(64 * 8 * 10 * 5);
   CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_attn_stamps), h.size() * 8));
