@@ -123,7 +123,8 @@ def end_to_end_node(n_workers: int, files_per_worker: int, chunk_s: float, batch
             return {"value": None, "error": (r.stdout + r.stderr)[-400:]}
         d = json.loads(lines[-1])
         keep = ("value", "unit", "workers", "files", "file_seconds", "audio_hours", "file_loop_span_s", "per_worker_steady_state",
-                "with_startup_and_model_construction", "launcher_wall_s", "host_cpus", "what")
+                "with_startup_and_model_construction", "launcher_wall_s", "host_cpus", "cpu_seconds_per_audio_hour",
+                "host_cores_busy", "what")
         return {k: d[k] for k in keep}
     except Exception as e:
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}

@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--chunk", type=float, default=10.0)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--timeout", type=float, default=600.0)
+    ap.add_argument("--launcher-args", default="", help="extra launcher options, space separated (e.g. --no_affinity)")
     args = ap.parse_args()
 
     import numpy as np  # noqa: F401
@@ -65,14 +66,18 @@ def main() -> None:
         cmd = [sys.executable, "-m", "vtc_amd.launcher", "node", "--gpus", str(args.workers)]
         if args.devices:
             cmd += ["--devices", args.devices]
+        cmd += args.launcher_args.split()
         cmd += ["--", "--config", str(root / "cfg.yml"), "--checkpoint", "synthetic:0", "--batch_size", str(args.batch)]
         env = dict(os.environ, PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
                   "TORCHELASTIC_RUN_ID"):
             env.pop(k, None)        # the workers are plain CLI processes, not ranks of the bench's process group
         t0 = time.time()
+        c0 = os.times()
         r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=args.timeout)
         wall = time.time() - t0
+        c1 = os.times()
+        cpu_s = (c1.children_user - c0.children_user) + (c1.children_system - c0.children_system)   # launcher + all workers
         if r.returncode != 0:
             raise RuntimeError(f"launcher exited with {r.returncode}: {(r.stdout + r.stderr)[-1500:]}")
         recs = [json.loads(l) for l in (root / "logs" / "benchmarks.jsonl").read_text().strip().splitlines()]
@@ -85,12 +90,15 @@ def main() -> None:
         span = max(x["extra"]["loop_end_unix"] for x in recs) - min(x["extra"]["loop_start_unix"] for x in recs)
         print(json.dumps({
             "metric": "VTC audio-hours/sec (node), end to end through the CLI: WAV files -> vtc_raw/vtc_merged/vtc_meta parquet",
-            "value": hours / span, "unit": "audio-hours/sec", "workers": args.workers, "devices": args.devices or "0..N-1",
+            "value": hours / span, "unit": "audio-hours/sec", "workers": args.workers, "devices": args.devices or "0..N-1", "launcher_args": args.launcher_args,
             "files": n_files, "file_seconds": args.seconds, "audio_hours": hours, "file_loop_span_s": span,
             "per_worker_steady_state": [round(x["total_audio_seconds"] / 3600.0 / x["wall_seconds"], 3) for x in recs],
             "per_worker_file_loop_s": [x["wall_seconds"] for x in recs],
             "with_startup_and_model_construction": hours / wall, "launcher_wall_s": wall, "raw_segments": n_raw,
             "chunk_duration_s": args.chunk, "batch": args.batch, "host_cpus": len(os.sched_getaffinity(0)),
+            # measured host budget: CPU time (user + system) of the launcher and all its workers, start-up and model
+            # construction included; host_cores_busy is what the run kept busy on average
+            "cpu_seconds": cpu_s, "cpu_seconds_per_audio_hour": cpu_s / hours, "host_cores_busy": cpu_s / wall,
             "what": "vtc_amd.launcher: one worker process per GPU, file-level sharding (--array_id/--array_count), no collective; "
                     "file I/O from /dev/shm, H2D, GPU front-end, forward, decode, segment rows, collar merge, parquet"}), flush=True)
     finally:
