@@ -23,7 +23,7 @@ struct WindowTable {          // device arrays, one entry per window of the batc
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatN = 65;
 constexpr int kStatSlots = 66;    // 65 moments + max |x| of the chunk (scales the fp16 split of conv0, below)
-constexpr int kStatChunk = 2048;  // conv0 frames per block
+constexpr int kStatChunk = 4096;  // conv0 frames per block (16 per thread: the 65 fp64 wave reductions at the end cost as much as 8 frames)
 
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, WindowTable wt, int L0,
                                                             double* __restrict__ partial /*[B][nchunk][66]*/) {
