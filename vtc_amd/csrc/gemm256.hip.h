@@ -535,9 +535,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int g = 0; g < 8; ++g) {
         const int row = row_of(g);
         const unsigned ro = row < p.M ? (unsigned)(row * p.ldc) : OOB;
+#if defined(VTC_ABL_LNRES) && (VTC_ABL_LNRES & 2)   // tools/gemm_bench timing ablation (results are garbage): no residual / statistics loads
+        h0[g] = u32x4{(unsigned)ro, 1u, 2u, 3u}; h1[g] = u32x2{4u, 5u}; st[g] = u32x2{0u, 0x3f800000u};
+#else
         h0[g] = __builtin_amdgcn_raw_buffer_load_b128(rh, ro == OOB ? OOB : (ro + (unsigned)col0) * 2u, 0, 0);
         h1[g] = __builtin_amdgcn_raw_buffer_load_b64(rh, ro == OOB ? OOB : (ro + (unsigned)col1) * 2u, 0, 0);
         st[g] = __builtin_amdgcn_raw_buffer_load_b64(rstat, row < p.M ? (unsigned)row * 8u : OOB, 0, 0);
+#endif
       }
       // The first row groups start as soon as THEIR loads are back (loads return in order and nothing else is pending, so
       // the compiler's waits are counted ones); the rest of the burst arrives under that arithmetic.  The partial statistics
@@ -566,6 +570,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           v[8 + c + 1] = fmaf(gv1[c + 1], fmaf(a_r, ub, b_r), acc1[mq][i][0][c + 1] + bv1[c + 1]);
         }
         // statistics of the row over this wave's 48 columns (4 lanes x 12), fixed order
+#if defined(VTC_ABL_LNRES) && (VTC_ABL_LNRES & 1)   // timing ablation: no row statistics
+        const float mean = v[0], qd = v[1];
+#else
         float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11]));
         sm += __shfl_xor(sm, 16);
         sm += __shfl_xor(sm, 32);
@@ -575,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         for (int k = 0; k < 12; ++k) { const float d = v[k] - mean; qd = fmaf(d, d, qd); }
         qd += __shfl_xor(qd, 16);
         qd += __shfl_xor(qd, 32);
+#endif
         const u32x2 pm = {__float_as_uint(mean), __float_as_uint(qd)};
         const u32x4 o0 = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
         const u32x2 o1 = {pack2<F16>(v[8], v[9]), pack2<F16>(v[10], v[11])};
