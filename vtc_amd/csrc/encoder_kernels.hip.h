@@ -482,15 +482,19 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
 // Positional-conv input: fp32 (B*T, 768) -> zero-padded group-major 16-bit (B, 16, T+128, 48) so the
 // k=128 window of output frame t is the contiguous slice rows [t, t+128) (pad 64 front, modeling_hubert.py:48-54).
 template <bool F16>
-__global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ h0, h16* __restrict__ out, int T) {
-  const int p = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(192) void posconv_pack_kernel(const float* __restrict__ h0, h16* __restrict__ out, int T) {
+  // one thread per 4 channels (48 % 4 == 0: they share a group): a 16-B load and an 8-B store; 4 padded positions per block
+  const int b = blockIdx.y;
   const int TP = T + 128;
-  const int t = p - 64;
-  const bool live = t >= 0 && t < T;
-  for (int c = threadIdx.x; c < 768; c += 256) {
-    const int g = c / 48, ci = c - g * 48;
-    const float v = live ? h0[((long long)b * T + t) * 768 + c] : 0.f;
-    out[(((long long)b * 16 + g) * TP + p) * 48 + ci] = to_h16<F16>(v);
+  const int c = threadIdx.x * 4, g = c / 48, ci = c - g * 48;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = blockIdx.x * 4 + k;
+    if (p >= TP) break;
+    const int t = p - 64;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T) v = *(const float4*)(h0 + ((long long)b * T + t) * 768 + c);
+    *(uint2*)(out + (((long long)b * 16 + g) * TP + p) * 48 + ci) = make_uint2(pack2<F16>(v.x, v.y), pack2<F16>(v.z, v.w));
   }
 }
 

@@ -414,7 +414,7 @@ int forward_impl(vtc_model* m, const float* wav, int nw, float* logits, hipStrea
 
   // ---- positional conv (16 groups x [T x 6144] x [6144 x 48]) + GELU + residual, then LayerNorm
   LAUNCH(m, PC_PACK, 0.0, (double)M * 768 * 6, s,
-         hipLaunchKernelGGL((posconv_pack_kernel<F16>), dim3(T + 128, nw), dim3(256), 0, s, m->h0, m->posin, T));
+         hipLaunchKernelGGL((posconv_pack_kernel<F16>), dim3((T + 128 + 3) / 4, nw), dim3(192), 0, s, m->h0, m->posin, T));
   LAUNCH(m, PC_GEMM, 2.0 * M * 768.0 * 48 * 128, 0.0, s,
          hipLaunchKernelGGL((posconv_kernel<F16>), dim3((T + kPcRows - 1) / kPcRows, 16, nw), dim3(256), 0, s, m->posin,
                             m->pos_w, m->pos_b, m->h0, m->tmp32, T));
