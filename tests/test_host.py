@@ -506,6 +506,32 @@ def test_xls_manifest(tmp_path):
         utils.load_manifest(tmp_path / "bad.xls")
 
 
+def test_reader_task_planning():
+    """pipeline/vtc.py::plan_reader_tasks: runs of short files become bundles of at most one batch of windows, 16 MB and 256
+    files; long, missing (size 0) and isolated files are tasks of their own; every file appears exactly once, in order."""
+    from vtc_amd.pipeline import vtc as cli
+    step, batch = 199 * 320, 128
+    sec = lambda s: 44 + int(s * 32000)                       # bytes of a mono 16 kHz PCM16 WAV of s seconds
+    sizes = [sec(3600)] + [sec(5)] * 100 + [0] + [sec(8)] * 3 + [sec(600)] + [sec(2)] + [sec(1800), sec(1)]
+    tasks = cli.plan_reader_tasks(sizes, step, batch)
+    assert [i for t in tasks for i in t] == list(range(len(sizes)))                       # a partition, in order
+    assert tasks[0] == [0]                                                                # the hour-long file alone
+    windows = lambda n: max(1, -(-(n // 2 - 400 + 1) // step))
+    for t in tasks:
+        if len(t) > 1:
+            assert all(0 < sizes[i] <= cli.BUNDLE_FILE_BYTES for i in t)
+            assert sum(windows(sizes[i]) for i in t) <= batch and sum(sizes[i] for i in t) <= cli.BUNDLE_BYTES and len(t) <= cli.BUNDLE_FILES
+    assert tasks[1] == list(range(1, 65)) and tasks[2] == list(range(65, 101))            # 2 windows per 5 s file: 64 files fill a batch
+    assert [101] in tasks and [102, 103, 104] in tasks and [105] in tasks                 # missing file; a short run; the 10-minute file
+    assert tasks[-3:] == [[106], [107], [108]]                                            # isolated short files between long ones
+    # many tiny files: capped by the file count, then by bytes
+    tiny = cli.plan_reader_tasks([sec(0.1)] * 600, step, batch)
+    assert [len(t) for t in tiny] == [128, 128, 128, 128, 88]                             # one window each: the batch caps first
+    big = cli.plan_reader_tasks([sec(120)] * 10, step, 4096)
+    assert [len(t) for t in big] == [4, 4, 2]                                             # 3.8 MB each: 16 MB per bundle
+    assert cli.plan_reader_tasks(sizes, step, batch, bundle=False) == [[i] for i in range(len(sizes))]
+
+
 def test_batch_size_recommendation():
     """reference src/pipeline/resources.py:180-196 for 4 s windows; scaled by the window length for other configs."""
     from vtc_amd.pipeline.vtc import recommend_vtc_batch_size as rec

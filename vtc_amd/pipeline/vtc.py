@@ -178,6 +178,29 @@ BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (i
 BUNDLE_FILES = 256
 
 
+def plan_reader_tasks(file_bytes: list, step: int, batch_size: int, bundle: bool = True) -> list:
+    """Reader tasks in manifest order: each task is a list of consecutive file indices.  A run of short files (<= BUNDLE_FILE_BYTES
+    each) becomes ONE task of up to one batch of windows (estimated from the size as if mono 16 kHz PCM16), BUNDLE_BYTES and
+    BUNDLE_FILES; a file that is long, of unknown size (0: missing), or alone in its run is a task of its own."""
+    tasks, i, n = [], 0, len(file_bytes)
+    while i < n:
+        first, nbytes, windows = i, 0, 0
+        while (bundle and i < n and i - first < BUNDLE_FILES and 0 < file_bytes[i] <= BUNDLE_FILE_BYTES
+               and nbytes + file_bytes[i] <= BUNDLE_BYTES):
+            w_est = max(1, -(-(file_bytes[i] // 2 - RF_SIZE + 1) // step))
+            if i > first and windows + w_est > batch_size:
+                break
+            windows += w_est
+            nbytes += file_bytes[i]
+            i += 1
+        if i - first >= 2:
+            tasks.append(list(range(first, i)))
+        else:
+            i = first + 1
+            tasks.append([first])
+    return tasks
+
+
 def stage_bundle(paths, engine) -> list:
     """Reader-thread stage for a run of short files (thousands of 1-30 s recordings: the per-file cost of stage_audio --
     a pinned allocation, an H2D copy, a front-end launch and a stream synchronisation each -- is then what bounds the run,
@@ -486,33 +509,27 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         inflight, nxt, inflight_bytes = deque(), 0, 0
         group, group_windows = [], 0
 
+        tasks = plan_reader_tasks([sizes.get(u, 0) for u in todo], step, batch_size, bundle)
+
         def top_up():
-            """Submit reader tasks in manifest order.  A task is one recording, or a bundle: a run of consecutive short
-            files (stage_bundle) of up to one batch of windows, so that thousands of 1-30 s files cost one reader task,
-            one copy and one front-end launch per forward instead of one each."""
+            """Submit reader tasks in manifest order (plan_reader_tasks: one recording, or a bundle of consecutive short files,
+            so that thousands of 1-30 s files cost one reader task, one copy and one front-end launch per forward)."""
             nonlocal nxt, inflight_bytes
             # two tasks in flight whatever their size (the one the GPU works on and the next one); beyond that only
-            # what fits the byte budget, so that a manifest of day-long recordings (3.7 GB of float32 each in HBM, plus the
-            # pinned staging) does not stage `prefetch` of them per worker.  `prefetch` sizes the reader pool, not this.
-            while nxt < total and (len(inflight) < 2 or
-                                   (len(inflight) < max_ahead and inflight_bytes + sizes.get(todo[nxt], 0) <= read_budget)):
-                first, nbytes, windows = nxt, 0, 0
-                while (bundle and nxt < total and nxt - first < BUNDLE_FILES and 0 < sizes.get(todo[nxt], 0) <= BUNDLE_FILE_BYTES
-                       and nbytes + sizes[todo[nxt]] <= BUNDLE_BYTES):
-                    w_est = max(1, -(-(sizes[todo[nxt]] // 2 - RF_SIZE + 1) // step))     # as if mono 16 kHz PCM16
-                    if nxt > first and windows + w_est > batch_size:
-                        break
-                    windows += w_est
-                    nbytes += sizes[todo[nxt]]
-                    nxt += 1
-                if nxt - first >= 2:
-                    idx = list(range(first, nxt))
-                    inflight.append((idx, nbytes, readers.submit(stage_bundle, [uid_to_path[todo[i]] for i in idx], engine)))
+            # what fits the byte budget, so that a manifest of day-long recordings (3.7 GB of float32 each in HBM) does not
+            # stage `prefetch` of them per worker.  `prefetch` sizes the reader pool, not this.
+            while nxt < len(tasks):
+                idx = tasks[nxt]
+                nbytes = sum(sizes.get(todo[i], 0) for i in idx)
+                if not (len(inflight) < 2 or (len(inflight) < max_ahead and inflight_bytes + nbytes <= read_budget)):
+                    break
+                if len(idx) > 1:
+                    fut = readers.submit(stage_bundle, [uid_to_path[todo[i]] for i in idx], engine)
                 else:
-                    nxt = first + 1
-                    nbytes = sizes.get(todo[first], 0)
-                    inflight.append(([first], nbytes, readers.submit(stage_audio, uid_to_path[todo[first]], engine)))
+                    fut = readers.submit(stage_audio, uid_to_path[todo[idx[0]]], engine)
+                inflight.append((idx, nbytes, fut))
                 inflight_bytes += nbytes
+                nxt += 1
 
         pending = None     # (items, launched): forward enqueued, decode not collected yet
         serial_gpu = os.environ.get("VTC_SERIAL_GPU_STAGE") == "1"    # diagnostic: collect right after launching (A/B timing)
