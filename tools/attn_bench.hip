@@ -10,6 +10,7 @@
 #include <vector>
 #include "attention.hip.h"
 #include "attention64.hip.h"
+#include "attention_persistent.hip.h"
 using namespace vtc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -52,6 +53,25 @@ int main(int argc, char** argv) {
       const double d = fabs((double)a - (double)c);
       if (d > worst) worst = d;
       ndiff += ref[i] != got[i];
+    }
+    {
+      CK(hipMemset(ctx, 0, M * 768 * 2));
+      const int n_items = nqb * nw * 12;
+      const int grid = n_items < 512 ? n_items : 512;
+      auto gop = [&]() { hipLaunchKernelGGL((attention_persistent_kernel<true>), dim3(grid), dim3(512), extra_lds, 0, qkv, ctx, T, nkt, nqb, n_items); };
+      gop(); gop(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) gop();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float msp; CK(hipEventElapsedTime(&msp, e0, e1)); msp /= iters;
+      std::vector<unsigned short> gp((size_t)M * 768);
+      CK(hipMemcpy(gp.data(), ctx, gp.size() * 2, hipMemcpyDeviceToHost));
+      size_t nd = 0; double w = 0;
+      for (size_t i = 0; i < ref.size(); ++i) {
+        if (ref[i] != gp[i]) { ++nd; _Float16 a, c; memcpy(&a, &ref[i], 2); memcpy(&c, &gp[i], 2); const double d = fabs((double)a - (double)c); if (d > w) w = d; }
+      }
+      printf("attention (persistent) nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n", nw, T,
+             msp * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / msp / 1e9, nd, ref.size(), w);
     }
     printf("attention64 nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n", nw, T,
            ms64 * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / ms64 / 1e9, ndiff, ref.size(), worst);
