@@ -127,8 +127,11 @@ int vtc_threshold_mask(vtc_model* m, const float* logits /*[dev]*/, int64_t n_fr
  * Limits: n_frames <= VTC_STATIC_DECODE_MAX_FRAMES (larger inputs are rejected with VTC_ERR_CAPACITY; use vtc_decode).
  * result[0] receives the number of intervals found (if it exceeds `cap` only the first `cap` were written; -1 if the run
  * lists were inconsistent: out_start / out_end / out_label are then left untouched, whatever they held before the call), result_summary = {max logit (NaN if a logit is non-finite, as vtc_decode_files), mean sigmoid}.
- * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two models) race;
- * nothing has to be cleared between calls (every word a call reads it has written itself). */
+ * All calls on one GPU share that GPU's array, so calls must not overlap in time on one GPU.  Calls on one stream are ordered
+ * by the stream.  A call on another stream (of any model) while the previous call's kernels are still pending is refused with
+ * VTC_ERR_ARG instead of racing: the library records an event behind each call (created in vtc_create, not here) and queries
+ * it.  Under stream capture the check is skipped (events may not be queried there): whoever replays such graphs on several
+ * streams orders them.  Nothing has to be cleared between calls (every word a call reads it has written itself). */
 #define VTC_STATIC_DECODE_MAX_FRAMES 262144   /* 87 min of audio at 20 ms per frame */
 #define VTC_STATIC_DECODE_BYTES ((8u << 20) + (1u << 17))
 int vtc_decode_static(vtc_model* m, const float* logits /*[dev]*/, int64_t n_frames, const float* lo_logit /*[host]*/,

@@ -105,3 +105,47 @@ def test_static_decode_equals_vtc_decode_twice_in_a_row():
     assert n == 4 * (lib.STATIC_DECODE_MAX_FRAMES // 2)
     assert np.array_equal(s[: n // 4], np.arange(0, lib.STATIC_DECODE_MAX_FRAMES, 2) * 320) and np.all(e - s == 400)
     eng.close()
+
+
+def test_static_decode_refuses_a_call_that_would_overlap_the_previous_one():
+    """All calls on a GPU share one scratch array (include/vtc_amd.h).  A call on another stream while the previous call's
+    kernels are pending is refused with VTC_ERR_ARG; the same stream, or the other stream once the work is done, is fine."""
+    from vtc_amd.engine import VtcEngine
+    L = lib.load()
+    eng = VtcEngine(O.make_weights(seed=0), n_labels=4, chunk_duration_s=1.0, max_batch=1, device=0)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    logits = torch.from_numpy(np.random.default_rng(5).standard_normal((3_001, 4)).astype(np.float32)).cuda()
+    want = eng.decode(logits, lo, hi)
+    cap = 4096
+    outs = [(torch.full((cap,), -7, dtype=torch.int64, device="cuda"), torch.full((cap,), -7, dtype=torch.int64, device="cuda"),
+             torch.full((cap,), -7, dtype=torch.int32, device="cuda"), torch.full((1,), -9, dtype=torch.int64, device="cuda"),
+             torch.zeros(2, dtype=torch.float64, device="cuda")) for _ in range(4)]
+
+    def call(k, stream):
+        s, e, lab, res, summ = outs[k]
+        return L.vtc_decode_static(eng._handle, C.c_void_p(logits.data_ptr()), int(logits.shape[0]), lo.ctypes.data_as(lib._f32p),
+                                   hi.ctypes.data_as(lib._f32p), C.c_void_p(s.data_ptr()), C.c_void_p(e.data_ptr()),
+                                   C.c_void_p(lab.data_ptr()), cap, C.c_void_p(res.data_ptr()), C.c_void_p(summ.data_ptr()),
+                                   C.c_void_p(stream.cuda_stream))
+
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(20_000_000)          # stream a is busy for >= 10 ms: the first call's kernels wait behind it
+    assert call(0, a) == lib.OK
+    rc = call(1, b)                            # would run beside the first call's kernels on the same scratch
+    assert rc == lib.ERR_ARG
+    with pytest.raises(lib.VtcError) as ei:
+        lib.check(rc, eng._handle)
+    assert "must not overlap" in str(ei.value)
+    assert call(2, a) == lib.OK                # same stream: ordered behind the first call
+    torch.cuda.synchronize()
+    assert call(3, b) == lib.OK                # nothing pending any more
+    torch.cuda.synchronize()
+    assert int(outs[1][3].item()) == -9        # the refused call launched nothing
+    for k in (0, 2, 3):
+        s, e, lab, res, summ = outs[k]
+        n = int(res.item())
+        assert n == len(want[0]) and np.array_equal(s.cpu().numpy()[:n], want[0]) and np.array_equal(e.cpu().numpy()[:n], want[1])
+        assert np.array_equal(lab.cpu().numpy()[:n], want[2]) and summ[0].item() == want[3] and summ[1].item() == want[4]
+    eng.close()

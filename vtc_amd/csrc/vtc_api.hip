@@ -58,6 +58,13 @@ static __device__ __align__(256) unsigned char scratch[VTC_STATIC_DECODE_BYTES];
 constexpr int kMaxDevices = 64;
 unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU
 std::mutex g_scratch_mu;
+// Overlap guard of vtc_decode_static: an event recorded behind each call (created with the scratch address, once per GPU).
+// A call on ANOTHER stream while that event is still pending would share the array with work in flight: it is refused
+// (VTC_ERR_ARG) instead of racing.  Calls on the same stream are ordered by the stream; calls under stream capture are not
+// checked (an event may not be queried there; the graph's owner orders its replays).
+hipEvent_t g_static_done[kMaxDevices] = {nullptr};
+hipStream_t g_static_stream[kMaxDevices] = {nullptr};
+bool g_static_pending[kMaxDevices] = {false};
 
 // Device weights of one transformer layer in the LayerNorm-free form (gemm256.hip.h): the LayerNorm in front of a GEMM is
 // folded into it (gamma into the 16-bit weights, beta into the bias, colsum for the mean), the LayerNorm behind a residual
@@ -566,6 +573,8 @@ int vtc_create(const vtc_spec* spec, const vtc_weights* w, int device, vtc_model
       void* ptr = nullptr;
       const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
       if (e != hipSuccess || !ptr) return bail(fail(m, VTC_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)));
+      if (hipEventCreateWithFlags(&g_static_done[device], hipEventDisableTiming) != hipSuccess)
+        return bail(fail(m, VTC_ERR_HIP, "hipEventCreate for the static decode's overlap guard failed"));
       g_scratch_ptr[device] = (unsigned char*)ptr;
     }
   }
@@ -839,6 +848,21 @@ int vtc_decode_static(vtc_model* m, const float* logits, int64_t n, const float*
   if (!base) return fail(m, VTC_ERR_HIP, "static scratch of device %d was not resolved", m->device);
   HIP_TRY(m, hipSetDevice(m->device));
   hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (s) HIP_TRY(m, hipStreamIsCapturing(s, &capture));
+  const bool guarded = capture == hipStreamCaptureStatusNone;
+  std::unique_lock<std::mutex> guard(g_scratch_mu, std::defer_lock);
+  if (guarded) {
+    guard.lock();   // held until this call's event is recorded: two host threads cannot both pass the check
+    if (g_static_pending[m->device] && g_static_stream[m->device] != s) {
+      const hipError_t q = hipEventQuery(g_static_done[m->device]);
+      (void)hipGetLastError();
+      if (q == hipErrorNotReady)
+        return fail(m, VTC_ERR_ARG, "vtc_decode_static: the previous call on device %d, on another stream, has not finished; "
+                    "calls on one GPU share one scratch array and must not overlap", m->device);
+      if (q != hipSuccess) return fail(m, VTC_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+    }
+  }
   const int nl = m->spec.n_labels;
   int* counts = (int*)(base + kStOffCounts);
   int* totals = (int*)(base + kStOffTotals);
@@ -859,6 +883,11 @@ int vtc_decode_static(vtc_model* m, const float* logits, int64_t n, const float*
                      nl, (long long)cap, (long long*)out_start, (long long*)out_end, out_label, (long long*)result, summary,
                      (double)n * nl, result_summary);
   HIP_TRY(m, hipGetLastError());
+  if (guarded) {
+    HIP_TRY(m, hipEventRecord(g_static_done[m->device], s));
+    g_static_stream[m->device] = s;
+    g_static_pending[m->device] = true;
+  }
   return VTC_OK;
 }
 
