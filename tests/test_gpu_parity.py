@@ -1071,6 +1071,50 @@ def test_cli_bundled_staging_equals_per_file_staging(tmp_path, monkeypatch):
     assert set(errs) == {"b40", "missing"} and "too short" in errs["b40"]
 
 
+def test_cli_reruns_files_that_overflow_fp16_with_bf16_storage(weights, tmp_path, monkeypatch):
+    """A checkpoint whose activations pass 65,504 gives NaN logits in fp16 storage.  The CLI runs such a file again with a
+    bf16 engine on the same weights instead of losing it (pipeline/vtc.py: `rescue`): the rows must be exactly those of a
+    run configured for bf16, and with engine.bf16_rescue: false the files are error rows as before."""
+    from vtc_amd.audio import write_wav
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    w = {k: np.asarray(v) for k, v in weights.items()}
+    key = "encoder.layers.5.feed_forward.intermediate_dense.weight"
+    w[key] = w[key] * 1.0e5                      # the FFN hidden state of layer 5 leaves the fp16 range for any input
+    np.savez(tmp_path / "hot.npz", **w)
+    names = []
+    for k, d in enumerate((2.5, 9.7, 0.8, 21.3)):
+        p = tmp_path / "audio" / f"h{k}.wav"
+        write_wav(p, synth.synth_audio(d, seed=1500 + k))
+        names.append(str(p))
+    for ds in ("resc", "bf", "off"):
+        (tmp_path / "manifests" / f"{ds}.csv").write_text("path\n" + "\n".join(names) + "\n")
+    base = "model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n"
+    (tmp_path / "f16.yml").write_text(base)
+    (tmp_path / "bf16.yml").write_text(base + "engine:\n  mfma_dtype: bf16\n")
+    (tmp_path / "off.yml").write_text(base + "engine:\n  bf16_rescue: false\n")
+    common = dict(checkpoint=str(tmp_path / "hot.npz"), batch_size=8, save_logits=True)
+    cli.main("resc", config=str(tmp_path / "f16.yml"), **common)
+    cli.main("bf", config=str(tmp_path / "bf16.yml"), **common)
+    cli.main("off", config=str(tmp_path / "off.yml"), **common)
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        a = pq.read_table(tmp_path / "output" / "resc" / kind / "shard_0.parquet")
+        b = pq.read_table(tmp_path / "output" / "bf" / kind / "shard_0.parquet")
+        assert json.dumps(a.to_pylist(), sort_keys=True) == json.dumps(b.to_pylist(), sort_keys=True), kind
+    meta = pq.read_table(tmp_path / "output" / "resc" / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert [r["uid"] for r in meta] == ["h0", "h1", "h2", "h3"] and not any(r["error"] for r in meta)
+    for k in range(4):       # the saved logits are the bf16 engine's, finite
+        a = torch.load(tmp_path / "output" / "resc" / "logits" / f"h{k}-logits_dict_t.pt", weights_only=True)
+        b = torch.load(tmp_path / "output" / "bf" / "logits" / f"h{k}-logits_dict_t.pt", weights_only=True)
+        assert all(torch.isfinite(a[l]).all() and torch.equal(a[l], b[l]) for l in a)
+    rec = [json.loads(l) for l in (tmp_path / "logs" / "benchmarks.jsonl").read_text().strip().splitlines()]
+    assert [r["extra"]["bf16_rescued_files"] for r in rec] == [4, 0, 0]
+    off = pq.read_table(tmp_path / "output" / "off" / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert all("non-finite" in (r["error"] or "") for r in off)
+
+
 def pa_buf(b):
     import pyarrow as pa
     return pa.BufferReader(b)

@@ -310,6 +310,10 @@ def gpu_collect(engine, launched, want_logits: bool):
     return out
 
 
+class NonFiniteLogits(ValueError):
+    """The recording's logits hold NaN / inf: an activation left the range of the 16-bit storage type."""
+
+
 def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | None):
     """Host stage: decoded runs -> the file's segment columns + meta row (reference vtc.py:252-281).  Columns, not one
     dict per segment: a block is (uid, onset, offset, duration, label_codes) with numpy arrays, joined into the shard's
@@ -318,7 +322,7 @@ def finish_file(decoded, uid: str, threshold: float, labels, save_to: Path | Non
     if not math.isfinite(max_logit) and not max_logit == -math.inf:
         # vtc_decode_collect marks a recording with NaN / inf logits by max_logit = NaN (include/vtc_amd.h): fp16 storage
         # overflowed somewhere upstream; such a file gets an error row, never an empty-looking valid one
-        raise ValueError("non-finite logits: an activation left the range of the 16-bit storage type (try engine.mfma_dtype: bf16)")
+        raise NonFiniteLogits("non-finite logits: an activation left the range of the 16-bit storage type (try engine.mfma_dtype: bf16)")
     if save_to is not None:
         torch.save({labels[j]: cpu_logits[:, j] for j in range(len(labels))}, save_to / f"{uid}-logits_dict_t.pt")
     onset, offset, duration, keep = intervals_to_columns(starts, ends)
@@ -634,6 +638,19 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 if not f.done():
                     f.set_exception(RuntimeError("run stopped before this file was processed"))
 
+    # A recording whose activations leave the fp16 range (65,504) comes back with NaN logits.  Rather than lose the file,
+    # it is run again, alone, by a second engine on the same weights with bf16 storage (same kernels, 8 bits of mantissa:
+    # DESIGN.md section 3 gives what that costs in accuracy).  Off with engine.bf16_rescue: false; pointless when the
+    # configured type is bf16 already.
+    can_rescue = bool(getattr(model_config.engine, "bf16_rescue", True)) and model_config.engine.mfma_dtype == "f16"
+    n_rescued = 0
+
+    def rescue(uid: str):
+        eng = model.rescue_engine(chunk_duration_s, min(batch_size, 16))
+        wav = stage_audio(uid_to_path[uid], eng)
+        decoded = gpu_stage(eng, wav, lo, hi, min(batch_size, 16), save_logits)
+        return decoded, finish_file(decoded, uid, threshold, labels, save_to)
+
     with ThreadPoolExecutor(max_workers=depth) as readers, ThreadPoolExecutor(max_workers=1) as gpu_thread:
         worker = gpu_thread.submit(gpu_worker, readers)
         try:
@@ -645,10 +662,21 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     _tick("finish", t_fin)
                     audio_seconds += decoded[5] / 16000.0
                 except Exception as e:  # per-file failure -> error row, run continues (reference vtc.py:245-249)
-                    n_errors += 1
-                    logger.warning(f"{uid}: {e}")
-                    meta_rows.append(vtc_error_row(uid, str(e)))
-                    continue
+                    rescued = None
+                    if isinstance(e, NonFiniteLogits) and can_rescue:
+                        try:
+                            decoded, rescued = rescue(uid)
+                            audio_seconds += decoded[5] / 16000.0
+                            n_rescued += 1
+                            logger.warning(f"{uid}: an activation left the fp16 range; the file was run again with bf16 storage")
+                        except Exception as e2:
+                            e = e2
+                    if rescued is None:
+                        n_errors += 1
+                        logger.warning(f"{uid}: {e}")
+                        meta_rows.append(vtc_error_row(uid, str(e)))
+                        continue
+                    segs, row = rescued
                 seg_blocks.append(segs)
                 meta_rows.append(row)
                 bytes_done += sizes.get(uid, 0)
@@ -669,6 +697,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     last_log = now
         finally:
             stop.set()          # an interrupt here must not leave the worker chewing through the rest of the manifest
+            model.close_rescue()
         worker.result()
 
     t_w = time.perf_counter()
@@ -680,7 +709,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     print(flush=True)
     logger.info("-" * 50)
     logger.info(f"Shard {shard_id} complete")
-    logger.info(f"  Files     : {total - n_errors}/{total}  ({n_errors} errors)")
+    logger.info(f"  Files     : {total - n_errors}/{total}  ({n_errors} errors" + (f", {n_rescued} re-run in bf16)" if n_rescued else ")"))
     logger.info(f"  Threshold : {threshold}")
     logger.info(f"  Segments  : {seg_df.num_rows:,} raw, {merged_df.num_rows:,} merged")
     logger.info(f"  Wall time : {hhmmss(wall)}   ({audio_seconds / 3600.0 / max(wall, 1e-9):.3f} audio-hours/s)")
@@ -691,7 +720,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     log_benchmark(step="vtc", dataset=dataset, n_files=total, wall_seconds=wall, total_audio_seconds=audio_seconds,
                   total_bytes=done_bytes, n_workers=1,
                   extra={"device": torch.cuda.get_device_name(dev_index), "shard_id": shard_id,
-                         "mfma_dtype": model_config.engine.mfma_dtype, "loop_start_unix": round(t0, 3), "loop_end_unix": round(t_end, 3),
+                         "mfma_dtype": model_config.engine.mfma_dtype, "bf16_rescued_files": n_rescued, "loop_start_unix": round(t0, 3), "loop_end_unix": round(t_end, 3),
                          "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()}})
 
 

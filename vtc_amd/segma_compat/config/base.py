@@ -29,6 +29,7 @@ class EngineConfig:
     mfma_dtype: str = "f16"        # "f16" | "bf16" MFMA operands (fp32 accumulate); DESIGN.md "Precision"
     max_batch: int = 0             # 0 = the batch_size handed to apply_model_on_audio
     synthetic_seed: int = 0        # used when the checkpoint path is "synthetic[:seed]"
+    bf16_rescue: bool = True       # CLI: a file whose activations leave the fp16 range is re-run with bf16 storage
 
 
 @dataclass

@@ -118,6 +118,7 @@ class VtcModel:
         self.config = config
         self.device = torch.device("cpu")
         self._engines = {}
+        self._rescue = {}
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, label_encoder, config, train: bool = False, **_):
@@ -152,6 +153,26 @@ class VtcModel:
             self._engines[key] = VtcEngine(self.state_dict_host, self.label_encoder.n_labels, chunk_duration_s,
                                            max_batch=key[1], mfma_dtype=self.config.engine.mfma_dtype, device=index)
         return self._engines[key]
+
+    def rescue_engine(self, chunk_duration_s: float, batch_size: int, device=None) -> VtcEngine:
+        """A second engine on the same weights with bf16 storage (8 exponent bits: no overflow at 65,504), for the rare
+        recording whose activations leave the fp16 range (pipeline/vtc.py).  Small batches: it runs one file at a time
+        beside the main engine.  Kept apart from engine()'s cache, which holds one engine per geometry."""
+        dev = torch.device(device) if device is not None else self.device
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = ("bf16", round(float(chunk_duration_s), 6), int(batch_size), index)
+        if key not in self._rescue:
+            for e in self._rescue.values():
+                e.close()
+            self._rescue.clear()
+            self._rescue[key] = VtcEngine(self.state_dict_host, self.label_encoder.n_labels, chunk_duration_s,
+                                          max_batch=int(batch_size), mfma_dtype="bf16", device=index)
+        return self._rescue[key]
+
+    def close_rescue(self):
+        for e in self._rescue.values():
+            e.close()
+        self._rescue.clear()
 
     def any_engine(self):
         return next(iter(self._engines.values()), None)
