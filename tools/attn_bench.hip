@@ -11,6 +11,8 @@
 #include "attention.hip.h"
 #include "attention64.hip.h"
 #include "attention_persistent.hip.h"
+#include "attention_pp.hip.h"
+#include "attention_b2.hip.h"
 using namespace vtc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -72,6 +74,41 @@ int main(int argc, char** argv) {
       }
       printf("attention (persistent) nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n", nw, T,
              msp * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / msp / 1e9, nd, ref.size(), w);
+    }
+    {
+      CK(hipMemset(ctx, 0, M * 768 * 2));
+      auto gop = [&]() { hipLaunchKernelGGL((attention_b2_kernel<true>), dim3(nqb, nw * 12), dim3(512), extra_lds, 0, qkv, ctx, T, nkt); };
+      gop(); gop(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) gop();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float msp; CK(hipEventElapsedTime(&msp, e0, e1)); msp /= iters;
+      std::vector<unsigned short> gp((size_t)M * 768);
+      CK(hipMemcpy(gp.data(), ctx, gp.size() * 2, hipMemcpyDeviceToHost));
+      size_t nd = 0;
+      for (size_t i = 0; i < ref.size(); ++i) nd += ref[i] != gp[i];
+      printf("attention (barrier every 2 tiles) nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ\n",
+             nw, T, msp * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / msp / 1e9, nd, ref.size());
+    }
+    for (int prio = 0; prio < 2; ++prio) {
+      CK(hipMemset(ctx, 0, M * 768 * 2));
+      auto gop = [&]() {
+        if (prio) hipLaunchKernelGGL((attention_pp_kernel<true, true>), dim3(nqb, nw * 12), dim3(512), extra_lds, 0, qkv, ctx, T, nkt);
+        else      hipLaunchKernelGGL((attention_pp_kernel<true, false>), dim3(nqb, nw * 12), dim3(512), extra_lds, 0, qkv, ctx, T, nkt);
+      };
+      gop(); gop(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) gop();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float msp; CK(hipEventElapsedTime(&msp, e0, e1)); msp /= iters;
+      std::vector<unsigned short> gp((size_t)M * 768);
+      CK(hipMemcpy(gp.data(), ctx, gp.size() * 2, hipMemcpyDeviceToHost));
+      size_t nd = 0; double w = 0;
+      for (size_t i = 0; i < ref.size(); ++i) {
+        if (ref[i] != gp[i]) { ++nd; _Float16 a, c; memcpy(&a, &ref[i], 2); memcpy(&c, &gp[i], 2); const double d = fabs((double)a - (double)c); if (d > w) w = d; }
+      }
+      printf("attention (ping-pong%s) nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n",
+             prio ? ", setprio" : "", nw, T, msp * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / msp / 1e9, nd, ref.size(), w);
     }
     printf("attention64 nw=%d T=%d: %.1f us  %.1f TFLOP/s; vs attention_kernel: %zu of %zu elements differ, worst |d| %.3g\n", nw, T,
            ms64 * 1e3, 4.0 * nw * 12 * (double)T * T * 64 / ms64 / 1e9, ndiff, ref.size(), worst);
