@@ -676,7 +676,8 @@ def test_cli_accepts_stereo_44k_file(weights, tmp_path, monkeypatch):
 
 def test_cli_flac_and_aiff_inputs_equal_wav(weights, tmp_path, monkeypatch):
     """The same PCM16 samples as .wav, .flac (library decoder) and .aiff give identical segments and meta rows through
-    the CLI; a 24-bit FLAC (float path) agrees with the oracle on its own samples; an .mp3 becomes an error row."""
+    the CLI; a 24-bit FLAC (float path) agrees with the oracle on its own samples; an .mp3 becomes an error row; an 8 kHz
+    G.711 mu-law WAV gives the rows of its expansion stored as PCM16."""
     import aifc, warnings
     from scipy.io import wavfile
     from oracle import flac_codec as FL
@@ -697,7 +698,19 @@ def test_cli_flac_and_aiff_inputs_equal_wav(weights, tmp_path, monkeypatch):
     x24 = np.clip(np.round(x.astype(np.float64) * (1 << 23)), -(1 << 23), (1 << 23) - 1).astype(np.int64)
     (tmp_path / "audio" / "b24.flac").write_bytes(FL.encode(x24, 16000, bps=24))
     (tmp_path / "audio" / "c.mp3").write_bytes(b"ID3" + bytes(64))
-    names = ["a_wav.wav", "a_flac.flac", "a_aiff.aiff", "b24.flac", "c.mp3"]
+    # 8-bit G.711 mu-law at 8 kHz (telephone speech) and the same samples, expanded with the Recommendation's table, as PCM16
+    import struct
+    from vtc_amd.audio import g711_table
+    x8 = np.interp(np.arange(int(21.3 * 8000)) / 8000.0, np.arange(len(x)) / 16000.0, x)
+    lin = np.clip(np.round(x8 * 32768), -32635, 32635).astype(np.int32)
+    mag = np.abs(lin) + 0x84
+    e = np.maximum(np.floor(np.log2(mag)).astype(np.int32) - 7, 0)
+    codes = (~(np.where(lin < 0, 0x80, 0) | (e << 4) | ((mag >> (e + 3)) & 0x0F)) & 0xFF).astype(np.uint8)
+    fmt = struct.pack("<HHIIHHH", 7, 1, 8000, 8000, 1, 8, 0)
+    body = b"WAVEfmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", codes.size) + codes.tobytes()
+    (tmp_path / "audio" / "d_ulaw.wav").write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    wavfile.write(tmp_path / "audio" / "d_lin.wav", 8000, g711_table("ulaw")[codes])
+    names = ["a_wav.wav", "a_flac.flac", "a_aiff.aiff", "b24.flac", "c.mp3", "d_ulaw.wav", "d_lin.wav"]
     (tmp_path / "manifests" / "mix.csv").write_text("path\n" + "".join(f"{tmp_path / 'audio' / n}\n" for n in names))
     (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
     cli.main("mix", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8, save_logits=True)
@@ -715,6 +728,9 @@ def test_cli_flac_and_aiff_inputs_equal_wav(weights, tmp_path, monkeypatch):
     ref = O.apply_model_on_waveform(weights, (x24 / float(1 << 23)).astype(np.float32), 4.0)
     assert got.shape == ref.shape and (got - ref).abs().max().item() <= LOGIT_TOL
     assert "codec" in meta["c"]["error"] and meta["b24"]["error"] == ""
+    assert len(by("d_ulaw")) > 0 and by("d_ulaw") == by("d_lin") and meta["d_ulaw"]["error"] == ""
+    la, lb = (torch.load(out / "logits" / f"{u}-logits_dict_t.pt", weights_only=True) for u in ("d_ulaw", "d_lin"))
+    assert all(torch.equal(la[l], lb[l]) for l in O.DEFAULT_LABELS)
 
 
 # ----------------------------------------------------------------------------- several recordings per call (clips)

@@ -659,6 +659,68 @@ def test_fast_wav_reader_matches_scipy(tmp_path):
         audio.read_pcm(tmp_path / "junk.wav")
 
 
+def test_g711_and_rf64_wav_files(tmp_path):
+    """WAV sub-formats beyond PCM / float: 8-bit G.711 A-law and mu-law (format tags 6 and 7: telephone-speech corpora) are
+    expanded with the Recommendation's tables, and RF64 / BW64 headers (64-bit sizes in a 'ds64' chunk, for recordings past
+    4 GB) are read.  The tables are pinned by G.711's own properties: the extreme and smallest values of the
+    Recommendation, and re-compression with the Recommendation's ENCODER (segment search: another algorithm) giving back
+    every code (mu-law 0x7F, 'negative zero', re-encodes as 0xFF: the one known exception)."""
+    import struct
+    from vtc_amd import audio
+
+    ulaw, alaw = audio.g711_table("ulaw"), audio.g711_table("alaw")
+    assert (ulaw[0x00], ulaw[0x80], ulaw[0xFF], ulaw[0x7F], ulaw[0xFE], ulaw[0x7E]) == (-32124, 32124, 0, 0, 8, -8)
+    assert (alaw[0xD5], alaw[0x55], alaw[0xAA], alaw[0x2A], alaw[0xD4], alaw[0x54]) == (8, -8, 32256, -32256, 24, -24)
+
+    def lin2ulaw(x):
+        sign = 0x80 if x < 0 else 0
+        x = min(abs(x), 32635) + 0x84
+        e = max(x.bit_length() - 8, 0)
+        return ~(sign | (e << 4) | ((x >> (e + 3)) & 0x0F)) & 0xFF
+
+    def lin2alaw(x):
+        sign = 0x80 if x >= 0 else 0
+        x = min(abs(x), 32767)
+        e = 0 if x < 256 else x.bit_length() - 8
+        m = x >> 4 if x < 256 else (x >> (e + 3)) & 0x0F
+        return (sign | (e << 4) | m) ^ 0x55
+
+    assert [c for c in range(256) if lin2ulaw(int(ulaw[c])) != c] == [0x7F]
+    assert [c for c in range(256) if lin2alaw(int(alaw[c])) != c] == []
+    for t in (ulaw, alaw):        # 255 / 256 distinct levels, odd symmetry
+        assert len(set(t.tolist())) >= 255 and sorted(t.tolist()) == sorted((-t.astype(np.int32)).tolist())
+
+    def wav(tag, bits, ch, sr, payload, magic=b"RIFF", extra=b"", data_size=None, ds64=None):
+        fmt = struct.pack("<HHIIHH", tag, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits) + (b"\0\0" if tag != 1 else b"")
+        body = b"WAVE" + (b"ds64" + struct.pack("<I", 28) + ds64 if ds64 else b"")
+        body += b"fmt " + struct.pack("<I", len(fmt)) + fmt
+        body += b"data" + struct.pack("<I", len(payload) if data_size is None else data_size) + payload + extra
+        return magic + struct.pack("<I", 0xFFFFFFFF if ds64 else len(body)) + body
+
+    rng = np.random.default_rng(21)
+    codes = rng.integers(0, 256, 4001 * 2, dtype=np.uint8)
+    for name, tag, table in (("a.wav", 6, alaw), ("u.wav", 7, ulaw)):
+        (tmp_path / name).write_bytes(wav(tag, 8, 2, 8000, codes.tobytes()))
+        got, sr = audio.read_pcm(tmp_path / name)
+        assert sr == 8000 and got.dtype == np.int16 and np.array_equal(got, table[codes].reshape(-1, 2))
+        mono = audio.read_audio(tmp_path / name)                                  # mix + 8 -> 16 kHz on the host route
+        assert mono.dtype == np.float32 and abs(len(mono) - 8002) <= 1 and np.abs(mono).max() <= 1.0
+    (tmp_path / "m.wav").write_bytes(wav(7, 8, 1, 16000, codes[:999].tobytes()))
+    dst = np.zeros(4096, dtype=np.int16)
+    assert audio.read_plain_wav_into(tmp_path / "m.wav", dst, 0) is None          # not PCM16: staged on its own, not bundled
+    got, _ = audio.read_pcm(tmp_path / "m.wav")
+    assert np.array_equal(got, ulaw[codes[:999]])
+
+    x = (rng.standard_normal(3000) * 9000).astype(np.int16)
+    ds64 = struct.pack("<QQQI", 0, x.nbytes, len(x), 0)
+    junk = b"LIST" + struct.pack("<I", 6) + b"trailr"                              # a chunk BEHIND the data: ds64's size must be used
+    for magic in (b"RF64", b"BW64"):
+        (tmp_path / "big.wav").write_bytes(wav(1, 16, 1, 16000, x.tobytes(), magic=magic, extra=junk, data_size=0xFFFFFFFF, ds64=ds64))
+        got, sr = audio.read_pcm(tmp_path / "big.wav")
+        assert sr == 16000 and got.dtype == np.int16 and np.array_equal(got, x)
+        assert audio.read_plain_wav_into(tmp_path / "big.wav", dst, 5) == 3000 and np.array_equal(dst[5:3005], x)
+
+
 def test_columnar_segments_and_meta_equal_the_scalar_forms():
     """The CLI gathers segments as column blocks (core.intervals.intervals_to_columns, metadata.vtc_meta_row_columns,
     utils.segments_table_from_blocks); they must give exactly the rows of the scalar mirror of the reference

@@ -1,8 +1,8 @@
 """Audio front-end of the hot path: file -> mono 16 kHz float32 in [-1, 1).
 
 The reference leaves decoding to segma (torchaudio/torchcodec, requirements.txt:393-394); the rule for
-non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float; own RIFF
-parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
+non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float, G.711 A-law /
+mu-law, RF64 / BW64 headers; own RIFF parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
 other rates are resampled with torchaudio's windowed-sinc polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
 The lossy formats of scripts/make_manifest.py:26-39 (mp3, ogg, opus, m4a, aac, wma) need codecs that are not available
 offline; they raise, which the pipeline turns into an error row.
@@ -36,15 +36,36 @@ def to_float32(data: np.ndarray) -> np.ndarray:
     return out
 
 
+def g711_table(law: str) -> np.ndarray:
+    """ITU-T G.711 expansion, 256 codes -> 16-bit linear PCM (the tables of the Recommendation, as every decoder has
+    them).  mu-law: complement the byte; value = ((mantissa << 3) + 132 << exponent) - 132, sign bit set = negative
+    (range +-32124).  A-law: XOR 0x55; exponent 0: (mantissa << 4) + 8, else ((mantissa << 4) + 264) << (exponent - 1);
+    sign bit set = POSITIVE (range +-32256)."""
+    code = np.arange(256, dtype=np.int32)
+    if law == "ulaw":
+        u = ~code & 0xFF
+        mag = ((((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)) - 0x84
+        out = np.where(u & 0x80, -mag, mag)
+    elif law == "alaw":
+        a = code ^ 0x55
+        e, m = (a >> 4) & 7, a & 0x0F
+        mag = np.where(e == 0, (m << 4) + 8, ((m << 4) + 0x108) << np.maximum(e - 1, 0))
+        out = np.where(a & 0x80, mag, -mag)
+    else:
+        raise ValueError(law)
+    return out.astype(np.int16)
+
+
 def _wav_layout(f):
-    """Header of a RIFF/WAVE file open at position 0: (dtype, channels, sample_rate, data offset, frames) for the two
-    formats the GPU front-end takes as they are (PCM16, float32), None for anything else."""
+    """Header of a RIFF/WAVE (or RF64 / BW64: 64-bit sizes in a 'ds64' chunk, for files past 4 GB) file open at position 0:
+    (kind, channels, sample_rate, data offset, frames) with kind np.int16 / np.float32 for the two formats the GPU front-end
+    takes as they are, "alaw" / "ulaw" for 8-bit G.711 (expanded to int16 by _fast_wav); None for anything else."""
     import struct
 
     head = f.read(12)
-    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+    if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64", b"BW64") or head[8:12] != b"WAVE":
         return None
-    fmt = None
+    fmt, data64 = None, None
     while True:
         hdr = f.read(8)
         if len(hdr) < 8:
@@ -58,33 +79,46 @@ def _wav_layout(f):
             if tag == 0xFFFE and size >= 40:                       # WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the tag
                 tag = struct.unpack("<H", body[24:26])[0]
             fmt = (tag, ch, sr, bits)
+        elif cid == b"ds64":
+            body = f.read(size + (size & 1))
+            if size >= 16:
+                data64 = struct.unpack("<Q", body[8:16])[0]
         elif cid == b"data":
             if fmt is None:
                 return None
             tag, ch, sr, bits = fmt
-            dtype = np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else None
-            if dtype is None or ch < 1:
+            kind = (np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else
+                    "alaw" if (tag == 6 and bits == 8) else "ulaw" if (tag == 7 and bits == 8) else None)
+            if kind is None or ch < 1:
                 return None
+            width = 1 if isinstance(kind, str) else np.dtype(kind).itemsize
             offset = f.tell()
             avail = os.fstat(f.fileno()).st_size - offset
+            if size == 0xFFFFFFFF and data64 is not None:
+                size = data64
             nbytes = min(size, avail) if size not in (0, 0xFFFFFFFF) else avail
-            return dtype, ch, int(sr), offset, nbytes // (ch * np.dtype(dtype).itemsize)
+            return kind, ch, int(sr), offset, nbytes // (ch * width)
         else:
             f.seek(size + (size & 1), 1)
 
 
 def _fast_wav(path: Path):
-    """Minimal RIFF/WAVE reader for the two formats the GPU front-end takes as they are (PCM16, float32): one header
-    parse and one read (small files) or a memory map (large ones).  Returns None for anything else - scipy handles it."""
+    """Minimal RIFF/WAVE reader for the formats the GPU front-end takes as they are (PCM16, float32; G.711 A-law / mu-law
+    is expanded to int16 first): one header parse and one read (small files) or a memory map (large ones).  Returns None
+    for anything else - scipy handles it."""
     with open(path, "rb") as f:
         lay = _wav_layout(f)
         if lay is None:
             return None
-        dtype, ch, sr, offset, n = lay
+        kind, ch, sr, offset, n = lay
+        dtype = np.uint8 if isinstance(kind, str) else kind
         if n * ch * np.dtype(dtype).itemsize >= (8 << 20):
             data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(n * ch,))
         else:
+            f.seek(offset)
             data = np.fromfile(f, dtype=dtype, count=n * ch)
+        if isinstance(kind, str):
+            data = g711_table(kind)[data]          # 8-bit companded -> int16: from here on the PCM16 route
         return (data.reshape(n, ch) if ch > 1 else data), sr
 
 
@@ -277,16 +311,8 @@ def sinc_resample(x: np.ndarray, sr_in: int) -> np.ndarray:
 def read_audio(path) -> np.ndarray:
     """Decode one file to mono 16 kHz float32.  Raises on anything unreadable; the host turns the
     exception into an error row (reference src/pipeline/vtc.py:245-249)."""
-    from scipy.io import wavfile
-
     path = Path(path)
-    if path.suffix.lower() not in (".wav", ".wave"):
-        data, sr = read_pcm(path)
-    else:
-        try:
-            sr, data = wavfile.read(str(path), mmap=True)
-        except ValueError:
-            sr, data = wavfile.read(str(path), mmap=False)   # 24-bit PCM cannot be memory-mapped
+    data, sr = read_pcm(path)
     x = to_float32(np.asarray(data))
     if x.ndim == 2:
         x = x.mean(axis=1, dtype=np.float32)
