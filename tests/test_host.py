@@ -711,6 +711,19 @@ def test_g711_and_rf64_wav_files(tmp_path):
     got, _ = audio.read_pcm(tmp_path / "m.wav")
     assert np.array_equal(got, ulaw[codes[:999]])
 
+    # AIFF-C carries the same two codecs ('ulaw' / 'alaw'; COMM's sampleSize says 16, the data is one byte per sample)
+    def aifc_g711(ctype, ch, payload):
+        rate80 = struct.pack(">HQ", 16383 + 12, 8000 << (63 - 12))                 # 8000 Hz as an 80-bit extended float
+        comm = struct.pack(">hIh", ch, len(payload) // ch, 16) + rate80 + ctype + b"\x00\x00"
+        ssnd = struct.pack(">II", 0, 0) + payload
+        body = b"AIFC" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd
+        return b"FORM" + struct.pack(">I", len(body)) + body
+
+    for ctype, table in ((b"ulaw", ulaw), (b"ALAW", alaw)):
+        (tmp_path / "g.aifc").write_bytes(aifc_g711(ctype, 2, codes[:2000].tobytes()))
+        got, sr = audio.read_pcm(tmp_path / "g.aifc")
+        assert sr == 8000 and got.dtype == np.int16 and np.array_equal(got, table[codes[:2000]].reshape(-1, 2))
+
     x = (rng.standard_normal(3000) * 9000).astype(np.int16)
     ds64 = struct.pack("<QQQI", 0, x.nbytes, len(x), 0)
     junk = b"LIST" + struct.pack("<I", 6) + b"trailr"                              # a chunk BEHIND the data: ds64's size must be used

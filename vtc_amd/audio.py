@@ -189,7 +189,8 @@ def decode_flac(data, verify_md5: bool = False, n_threads: int | None = None):
 
 
 def decode_aiff(data):
-    """AIFF / AIFF-C with uncompressed PCM ('NONE', 'twos', 'sowt', 'fl32'/'FL32') -> (samples, sample_rate)."""
+    """AIFF / AIFF-C with uncompressed PCM ('NONE', 'twos', 'sowt', 'fl32'/'FL32') or G.711 ('ulaw', 'alaw') ->
+    (samples, sample_rate)."""
     import struct
 
     buf = memoryview(data)
@@ -214,10 +215,13 @@ def decode_aiff(data):
         raise ValueError("AIFF file without COMM or SSND chunk")
     ch, nframes, bits, rate, ctype = comm
     start, nbytes = ssnd
-    width = (bits + 7) // 8
+    g711 = {b"ulaw": "ulaw", b"ULAW": "ulaw", b"alaw": "alaw", b"ALAW": "alaw"}.get(ctype)
+    width = 1 if g711 else (bits + 7) // 8          # AIFF-C G.711: one byte per sample whatever COMM's sampleSize says (16)
     n = min(nframes, nbytes // (width * ch)) if ch > 0 and width > 0 else 0
     raw = np.frombuffer(buf, dtype=np.uint8, count=n * ch * width, offset=start)
-    if ctype in (b"fl32", b"FL32"):
+    if g711:
+        x = g711_table(g711)[raw]
+    elif ctype in (b"fl32", b"FL32"):
         x = raw.view(">f4").astype(np.float32)
     elif ctype in (b"NONE", b"twos", b"sowt"):
         order = "<" if ctype == b"sowt" else ">"
