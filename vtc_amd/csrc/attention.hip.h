@@ -47,7 +47,32 @@ __device__ long long g_attn_blk[4096 * 4];             // [block][entry, first t
 template <bool F16>
 __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx, int T, int nkt) {
   __shared__ __attribute__((aligned(16))) char smem[kAttnStages * kAttnStage];
-  const int b = blockIdx.y / 12, h = blockIdx.y - b * 12;
+  // XCD-aware block -> (query block, window x head) map.  Workgroups go to the 8 XCDs round-robin in launch order
+  // (x fastest), so with the plain map the query blocks of one head sit on different XCDs and each fetches the head's K / V
+  // through its own L2.  Here a run of 8 * nqb consecutive workgroups is 8 heads x nqb query blocks with the query block
+  // changing every 8 workgroups: the blocks that share K / V share an XCD (and still start within a few microseconds of
+  // each other).  Heads beyond the last full run of 8 keep the plain order.
+  int qb_, bh_;
+  {
+    const int nqb = gridDim.x, nbh = gridDim.y;
+    const int L = blockIdx.y * nqb + blockIdx.x;
+    const int run = 8 * nqb;
+#ifdef VTC_ATTN_PLAIN_MAP   // tools/attn_bench A/B: every head in the plain order
+    const int full = 0, bh_base = 0;
+#else
+    const int full = (nbh / 8) * run, bh_base = (nbh / 8) * 8;
+#endif
+    if (L < full) {
+      const int r_ = L % run;
+      qb_ = r_ >> 3;
+      bh_ = (L / run) * 8 + (r_ & 7);
+    } else {
+      qb_ = (L - full) % nqb;
+      bh_ = bh_base + (L - full) / nqb;
+    }
+  }
+  const int qblock = qb_, bh = bh_;
+  const int b = bh / 12, h = bh - b * 12;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long rowbase = (long long)b * T;
@@ -66,7 +91,7 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const h16* __restrict
     __builtin_amdgcn_global_load_lds(GPTR(src + 1536 + v_chunk * 8), LPTR(dst + 8192), 16, 0, 0);
   };
 
-  const int q0 = (blockIdx.x * kAttnWaves + wave) * 32;
+  const int q0 = (qblock * kAttnWaves + wave) * 32;
   const bool active = q0 < T;   // wave-uniform; idle waves still stage and hit the barriers
   const int r = lane & 31, hh = lane >> 5;
 
