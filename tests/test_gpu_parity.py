@@ -1087,6 +1087,52 @@ def test_cli_bundled_staging_equals_per_file_staging(tmp_path, monkeypatch):
     assert set(errs) == {"b40", "missing"} and "too short" in errs["b40"]
 
 
+def test_cli_window_packing_equals_whole_recordings_per_forward(tmp_path, monkeypatch):
+    """Window packing (pipeline/vtc.py::pack_forward): recordings share forwards window by window, so a recording may be cut
+    over two or more forwards.  All three tables and the saved logits must equal those of the same manifest run with whole
+    recordings per forward (VTC_NO_PACK=1, round 2's grouping): windows are independent, so the rows are bit-identical.
+    The manifest holds recordings of just under one batch (the 61-of-64 case in small: 15 windows of a 16-window batch),
+    of several batches, one long enough to run alone, short ones, a too-short and a missing file."""
+    from vtc_amd.audio import write_wav
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    rng = np.random.default_rng(91)
+    durs = [58.0] * 6 + [100.0, 3.0, 58.0, 0.02, 1.0, 230.0, 58.0, 58.0, 600.0, 7.5, 58.0, 58.0, 12.0, 58.0, 101.3, 58.0, 58.0, 4.0]
+    names = []
+    for k, d in enumerate(durs):
+        p = tmp_path / "audio" / f"p{k:02d}.wav"
+        write_wav(p, synth.synth_audio(float(d) + float(rng.uniform(0, 0.5)) * (d > 1), seed=1500 + k))
+        names.append(str(p))
+    names.insert(11, str(tmp_path / "audio" / "missing.wav"))
+    for ds in ("pk", "np"):
+        (tmp_path / "manifests" / f"{ds}.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    cli.main("pk", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=16, prefetch=3, save_logits=True)
+    stats = dict(cli.PACK_STATS)
+    step = 199 * 320
+    packed_windows = sum(-(-(int(d * 16000) - 399) // step) for d in durs if 0.03 < d < 500)
+    assert stats["forwards"] > 0 and abs(stats["windows"] - packed_windows) <= len(durs)      # every short recording went through it
+    print(f"packed forwards: {stats}")
+    assert stats["windows"] / stats["forwards"] > 8.0     # mostly full forwards of 16 (a flush whenever the readers lag is allowed)
+    monkeypatch.setenv("VTC_NO_PACK", "1")
+    cli.main("np", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=16, prefetch=3, save_logits=True)
+    assert cli.PACK_STATS["forwards"] == 0
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        a = pq.read_table(tmp_path / "output" / "pk" / kind / "shard_0.parquet")
+        b = pq.read_table(tmp_path / "output" / "np" / kind / "shard_0.parquet")
+        assert a.num_rows == b.num_rows and a.num_rows > 0
+        assert json.dumps(a.to_pylist(), sort_keys=True) == json.dumps(b.to_pylist(), sort_keys=True), kind
+    meta = pq.read_table(tmp_path / "output" / "pk" / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert [r["uid"] for r in meta] == [Path(n).stem for n in names]
+    assert {r["uid"] for r in meta if r["error"]} == {"p09", "missing"}
+    for uid in ("p00", "p06", "p11", "p14", "p23"):
+        a = torch.load(tmp_path / "output" / "pk" / "logits" / f"{uid}-logits_dict_t.pt", weights_only=True)
+        b = torch.load(tmp_path / "output" / "np" / "logits" / f"{uid}-logits_dict_t.pt", weights_only=True)
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a), uid
+
+
 def test_cli_reruns_files_that_overflow_fp16_with_bf16_storage(weights, tmp_path, monkeypatch):
     """A checkpoint whose activations pass 65,504 gives NaN logits in fp16 storage.  The CLI runs such a file again with a
     bf16 engine on the same weights instead of losing it (pipeline/vtc.py: `rescue`): the rows must be exactly those of a

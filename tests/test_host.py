@@ -532,6 +532,57 @@ def test_reader_task_planning():
     assert cli.plan_reader_tasks(sizes, step, batch, bundle=False) == [[i] for i in range(len(sizes))]
 
 
+def test_window_packing_plan_and_stitching():
+    """pipeline/vtc.py::pack_forward with a stand-in engine on the CPU (the plan and the stitching are host logic): the
+    stand-in writes, for every kept frame of every window, the first sample of that frame's receptive field.  Whatever
+    way recordings are cut over forwards, a recording's stitched rows must then be wav[g * 320] for g < frames(n) --
+    i.e. the window plan is vtc_infer_waveform's (step T * 320, zero-padded tail, frames inside the audio), nothing is
+    lost or doubled at a cut, and every forward but the last is full."""
+    import torch
+    from collections import deque
+    from vtc_amd.pipeline import vtc as cli
+
+    class Stub:
+        device, n_labels, window_samples, frames_per_window = torch.device("cpu"), 2, 64000, 199
+        step = 199 * 320
+        calls = []
+
+        def forward_windows(self, wav, start, valid, dst, keep, logits):
+            assert wav.dim() == 1 and wav.is_contiguous()
+            assert len(start) <= 8 and int((start + valid).max()) <= wav.numel()
+            self.calls.append(len(start))
+            for s, v, d, k in zip(start, valid, dst, keep):
+                assert 0 < k <= 199 and 400 <= v <= 64000 and (k - 1) * 320 + 400 <= v
+                for lab in range(2):
+                    logits[d:d + k, lab] = wav[s:s + k * 320:320] + lab
+
+    eng, batch = Stub(), 8
+    rng = np.random.default_rng(3)
+    lens = [64000 * 3 + 7, 400, 63680 + 399, 63680 + 400, 64000, 5000, 64000 * 11 + 12345, 719, 64000 * 20, 4800, 640000]
+    wavs = [torch.from_numpy(rng.standard_normal(n).astype(np.float32)) for n in lens]
+    carry, queued, got = deque(), 0, {}
+    for i, w in enumerate(wavs):
+        n_win = -(-(w.numel() - 400 + 1) // eng.step)
+        carry.append(cli.OpenRecording(i, w, n_win))
+        queued += n_win
+        while queued >= batch or (i == len(wavs) - 1 and queued):
+            nw = min(batch, queued)
+            done, out = cli.pack_forward(eng, carry, nw)
+            queued -= nw
+            if done:
+                logits, rows, n_samples = cli.packed_decode_input(done, out)
+                assert n_samples == [o.n for o in done] and rows[-1] == logits.shape[0]
+                for k, o in enumerate(done):
+                    got[o.i] = logits[int(rows[k]):int(rows[k + 1])].clone()
+    assert not carry and sorted(got) == list(range(len(wavs)))
+    assert all(c == batch for c in eng.calls[:-1]) and sum(eng.calls) == sum(-(-(n - 399) // eng.step) for n in lens)
+    for i, w in enumerate(wavs):
+        frames = (w.numel() - 400) // 320 + 1
+        assert got[i].shape == (frames, 2), i
+        want = w[:frames * 320:320]
+        assert torch.equal(got[i][:, 0], want) and torch.equal(got[i][:, 1], want + 1), i
+
+
 def test_batch_size_recommendation():
     """reference src/pipeline/resources.py:180-196 for 4 s windows; scaled by the window length for other configs."""
     from vtc_amd.pipeline.vtc import recommend_vtc_batch_size as rec

@@ -41,7 +41,7 @@ import torch
 from ..audio import read_pcm, read_plain_wav_into
 from ..core.intervals import intervals_to_columns
 from ..core.metadata import vtc_error_row, vtc_meta_row_columns
-from ..engine import RF_SIZE
+from ..engine import RF_SIZE, RF_STEP
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -60,6 +60,7 @@ _TLS = threading.local()
 STAGE_SECONDS = {"read": 0.0, "read_file": 0.0, "read_stage": 0.0, "read_sync": 0.0, "gpu_wait": 0.0, "gpu_run": 0.0,
                  "gpu_launch": 0.0, "gpu_collect": 0.0, "finish": 0.0, "write": 0.0}
 _TIMER_LOCK = threading.Lock()
+PACK_STATS = {"forwards": 0, "windows": 0}     # packed forwards of the last run and the windows they held (main, gpu_worker)
 
 
 def _tick(name: str, t0: float) -> None:
@@ -176,6 +177,95 @@ STAGE_CHUNK_BYTES = 64 << 20       # long recordings cross PCIe in pieces of thi
 BUNDLE_FILE_BYTES = 4 << 20        # files up to this size (~2 min of 16 kHz PCM16) are staged in bundles
 BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (int16 samples of one bundle)
 BUNDLE_FILES = 256
+PACK_BATCHES = 8                   # recordings of fewer than this many batches of windows share forwards window by window
+
+
+class OpenRecording:
+    """A staged recording some of whose windows have not run yet (window packing, `pack_forward`)."""
+    __slots__ = ("i", "wav", "n", "n_win", "next_w", "parts")
+
+    def __init__(self, i: int, wav: torch.Tensor, n_win: int):
+        self.i, self.wav, self.n, self.n_win, self.next_w, self.parts = i, wav, int(wav.numel()), n_win, 0, []
+
+
+def pack_forward(engine, carry: deque, n_windows: int):
+    """One forward over the next n_windows windows of the recordings queued in `carry`, whatever recording they belong to:
+    the last windows of one recording, whole recordings, and the first windows of another may share it, so that every
+    forward but a run's last is FULL.  (A 600 s recording is 61 windows of 10 s: alone it leaves 3 of a 64-window batch
+    empty, and twenty-two of them fit 21 forwards.)  Windows are independent (a frame's logits do not depend on its
+    batch mates: tests/test_gpu_parity.py::test_full_size_batch64_10s_properties), so the rows are bit-identical to those
+    of the recording run alone.  The window plan per recording is vtc_infer_waveform's (step T * 320, zero-padded tail,
+    frames whose receptive field lies in the audio).  Enqueues only; returns (recordings completed by this forward, each with
+    its stitched logits in `parts`, in queue order; the forward's logits buffer)."""
+    W, T, step, nl = engine.window_samples, engine.frames_per_window, engine.step, engine.n_labels
+    cur = torch.cuda.current_stream(engine.device) if torch.device(engine.device).type == "cuda" else None
+    # plain Python lists, converted once: with thousands of 1-10 s recordings per second this runs per recording, under the GIL
+    # the reader threads and the row-building thread also need
+    segs, runs, start, valid, keep, dst = [], [], [], [], [], []
+    need, base, rows = n_windows, 0, 0
+    while need and carry:
+        o = carry[0]
+        w0, n = o.next_w, o.n
+        cnt = min(need, o.n_win - w0)
+        o.next_w = w0 + cnt
+        need -= cnt
+        if o.next_w == o.n_win:
+            carry.popleft()
+        a, b = w0 * step, min(n, (w0 + cnt - 1) * step + W)
+        if w0 == 0 and cur is not None:
+            o.wav.record_stream(cur)          # staged on a reader thread's stream
+        piece = o.wav if (a == 0 and b == n) else o.wav[a:b]
+        # pieces that follow each other in one device array (a bundle of short files, stage_bundle) are one run: no copy
+        # (adjacent blocks of different allocations do not count: the storage must be the same)
+        ptr, store = piece.data_ptr(), piece.untyped_storage().data_ptr()
+        if runs and runs[-1][2] == ptr and runs[-1][3] == store:
+            runs[-1][1] += b - a
+            runs[-1][2] += 4 * (b - a)
+        else:
+            runs.append([piece, b - a, ptr + 4 * (b - a), store])
+        off, r0 = base - a, rows
+        for w in range(w0, w0 + cnt):
+            s0 = w * step
+            rem = n - s0
+            k = (rem - RF_SIZE) // RF_STEP + 1
+            k = k if k < T else T
+            start.append(off + s0)
+            valid.append(rem if rem < W else W)
+            keep.append(k)
+            dst.append(rows)
+            rows += k
+        segs.append((o, r0, rows))
+        base += b - a
+    pieces = [r[0] if r[1] == r[0].numel() else torch.as_strided(r[0], (r[1],), (1,), r[0].storage_offset()) for r in runs]
+    # several runs: one copy of <= a batch of windows (41 MB at 64 x 10 s, ~20 us) in front of a 10 ms forward
+    arena = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
+    out = torch.empty((rows, nl), dtype=torch.float32, device=engine.device)
+    with torch.no_grad():
+        engine.forward_windows(arena, np.array(start, dtype=np.int64), np.array(valid, dtype=np.int32),
+                               np.array(dst, dtype=np.int64), np.array(keep, dtype=np.int32), out)
+    done = []
+    for o, r0, r1 in segs:
+        o.parts.append((out, r0, r1))         # sliced only when needed (packed_decode_input)
+        if o.next_w == o.n_win:
+            done.append(o)
+    return done, out
+
+
+def packed_decode_input(done: list, out: torch.Tensor):
+    """(logits, file_rows, n_samples) of the recordings a forward completed, in the form gpu_decode_launch takes: the rows of
+    the forward's own buffer when every recording lies inside it (they are consecutive: only a forward's first recording
+    can have earlier parts and only its last one can be incomplete), otherwise one concatenation."""
+    rows = np.zeros(len(done) + 1, dtype=np.int64)
+    single = True
+    for k, o in enumerate(done):
+        rows[k + 1] = rows[k] + sum(r1 - r0 for _, r0, r1 in o.parts)
+        single = single and len(o.parts) == 1
+    if single:
+        a = done[0].parts[0][1]
+        logits = out[a:a + int(rows[-1])]
+    else:
+        logits = torch.cat([t[r0:r1] for o in done for t, r0, r1 in o.parts])
+    return logits, rows, [o.n for o in done]
 
 
 def plan_reader_tasks(file_bytes: list, step: int, batch_size: int, bundle: bool = True) -> list:
@@ -505,6 +595,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     read_budget = int(float(os.environ.get("VTC_READ_BUDGET_GB", "4")) * (1 << 30))
     max_ahead = 256
     bundle = not no_group and os.environ.get("VTC_NO_BUNDLE") != "1"     # A/B switch: stage every file on its own
+    pack = not no_group and os.environ.get("VTC_NO_PACK") != "1"         # A/B switch: whole recordings per forward (round 2's grouping)
+    PACK_STATS["forwards"] = PACK_STATS["windows"] = 0
 
     def gpu_worker(readers):
         """Pulls staged recordings in manifest order; recordings shorter than a batch are grouped until the batch is
@@ -537,6 +629,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
 
         pending = None     # (items, launched): forward enqueued, decode not collected yet
         serial_gpu = os.environ.get("VTC_SERIAL_GPU_STAGE") == "1"    # diagnostic: collect right after launching (A/B timing)
+        carry, carry_windows = deque(), 0      # window packing: recordings with windows still to run (pack_forward)
 
         def drain():
             """Collect the batch whose forward + decode are in flight (host sync) and publish its results."""
@@ -563,6 +656,48 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     results[i].set_result(gpu_stage(engine, w, lo, hi, batch_size, save_logits))
                 except Exception as e1:
                     results[i].set_exception(e1)
+
+        def redo_alone(victims, e):
+            """A packed forward (or its decode) failed: every recording it touched runs again on its own."""
+            logger.warning(f"packed forward failed ({e}); {len(victims)} recordings run one by one")
+            engine.decode_abandon()
+            for i, w in victims:
+                try:
+                    results[i].set_result(gpu_stage(engine, w, lo, hi, batch_size, save_logits))
+                except Exception as e1:
+                    results[i].set_exception(e1)
+
+        def pump(flush: bool):
+            """Window packing: run full forwards while the queued recordings hold a batch of windows (with `flush`, also the
+            partial one that is left), each in the order forward(k) -> collect(k-1) -> decode_launch(recordings that forward k
+            completed)."""
+            nonlocal carry_windows, pending
+            while carry_windows >= batch_size or (flush and carry_windows):
+                nw = min(batch_size, carry_windows)
+                touched = [(o.i, o.wav) for o in carry]
+                t_run = time.perf_counter()
+                try:
+                    done, out = pack_forward(engine, carry, nw)
+                except Exception as e:
+                    carry.clear()
+                    carry_windows = 0
+                    drain()
+                    redo_alone(touched, e)
+                    return
+                carry_windows -= nw
+                PACK_STATS["forwards"] += 1
+                PACK_STATS["windows"] += nw
+                _tick("gpu_launch", t_run)
+                drain()
+                if done:
+                    items = [(o.i, o.wav) for o in done]
+                    try:
+                        pending = (items, gpu_decode_launch(engine, packed_decode_input(done, out), lo, hi, save_logits))
+                    except Exception as e:
+                        redo_alone(items, e)
+                    if serial_gpu:
+                        drain()
+                _tick("gpu_run", t_run)
 
         def run_group():
             """Enqueue the forward of the current group, collect the previous group (its forward and decode were
@@ -597,6 +732,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 top_up()
                 if not fut.done():
                     run_group()          # the next recording is not staged yet: do not hold a partial batch back
+                    pump(True)
                     t_run = time.perf_counter()
                     drain()              # ... and publish what is in flight instead of sitting on it while waiting
                     _tick("gpu_run", t_run)
@@ -613,7 +749,13 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                         results[i].set_exception(wav)
                         continue
                     n_win = -(-(int(wav.numel()) - RF_SIZE + 1) // step)
+                    if pack and n_win < PACK_BATCHES * batch_size:
+                        carry.append(OpenRecording(i, wav, n_win))
+                        carry_windows += n_win
+                        pump(False)
+                        continue
                     if no_group or n_win >= batch_size:
+                        pump(True)       # manifest order: what is queued runs before the long recording
                         run_group()
                         group, group_windows = [(i, wav)], n_win
                         run_group()
@@ -625,6 +767,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                     if group_windows >= batch_size:
                         run_group()
             run_group()
+            pump(True)
             drain()
         except BaseException as e:       # never leave the consumer waiting on a future that will not resolve
             for f in results:
@@ -721,6 +864,7 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                   total_bytes=done_bytes, n_workers=1,
                   extra={"device": torch.cuda.get_device_name(dev_index), "shard_id": shard_id,
                          "mfma_dtype": model_config.engine.mfma_dtype, "bf16_rescued_files": n_rescued, "loop_start_unix": round(t0, 3), "loop_end_unix": round(t_end, 3),
+                         "packed_forwards": PACK_STATS["forwards"], "packed_windows": PACK_STATS["windows"],
                          "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()}})
 
 
