@@ -28,6 +28,7 @@ import sys
 import tarfile
 import threading
 import time
+from collections import deque
 from pathlib import Path
 
 import numpy as np
@@ -39,6 +40,7 @@ import torch
 from ..audio import decode_flac, to_float32
 from ..core.intervals import intervals_to_columns
 from ..engine import RF_SIZE
+from ..packing import OpenRecording, pack_forward, packed_decode_input
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -231,6 +233,35 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         if per_clip:
             drain()
 
+    # Window packing (pipeline/vtc.py::pack_forward): clips share forwards window by window, so every forward but the last
+    # is full.  Grouping whole clips until a batch is reached overshoots it by up to a clip, and the overshoot (a few
+    # windows) then ran as a forward of its own.
+    carry, carry_windows = deque(), 0
+
+    def pump(final: bool):
+        nonlocal carry_windows, pending
+        while carry_windows >= batch_size or (final and carry_windows):
+            nw = min(batch_size, carry_windows)
+            touched = [(o.i, o.wav) for o in carry]
+            try:
+                done, out = pack_forward(engine, carry, nw)
+            except Exception as e:
+                carry.clear()
+                carry_windows = 0
+                drain()
+                redo(touched, e)
+                return
+            carry_windows -= nw
+            drain()
+            if done:
+                items = [(o.i, o.wav) for o in done]
+                try:
+                    logits, file_rows, _ = packed_decode_input(done, out)
+                    engine.decode_launch(logits, file_rows, lo, hi)
+                    pending = (items, logits)
+                except Exception as e:
+                    redo(items, e)
+
     # Reader thread: tar members -> PCM in memory (FLAC through the library's decoder, outside the GIL), a bounded queue
     # ahead of the GPU loop.  Order is the tar order, as in the reference.
     todo: queue.Queue = queue.Queue(maxsize=4 * max(batch_size, 16))
@@ -279,16 +310,21 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
                 logger.warning(f"{clip_id}: {e}")
                 n_errors += 1
                 continue
-            group.append((clip_id, wav))
-            group_windows += max(1, -(-(int(wav.numel()) - RF_SIZE + 1) // step))
-            if per_clip or group_windows >= batch_size:
+            n_win = max(1, -(-(int(wav.numel()) - RF_SIZE + 1) // step))
+            if per_clip:
+                group.append((clip_id, wav))
                 flush()
+            else:
+                carry.append(OpenRecording(clip_id, wav, n_win))
+                carry_windows += n_win
+                pump(False)
             now = time.time()
             if now - last_log_t >= 60:
                 rate = n_processed / max(now - t0, 1e-9)
                 logger.info(f"  {n_processed} processed, {n_skipped} skipped, {n_errors} errors  ({rate:.1f} clips/s)")
                 last_log_t = now
         flush()
+        pump(True)
         drain()
     finally:
         stop.set()

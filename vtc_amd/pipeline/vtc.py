@@ -41,7 +41,8 @@ import torch
 from ..audio import read_pcm, read_plain_wav_into
 from ..core.intervals import intervals_to_columns
 from ..core.metadata import vtc_error_row, vtc_meta_row_columns
-from ..engine import RF_SIZE, RF_STEP
+from ..engine import RF_SIZE
+from ..packing import OpenRecording, pack_forward, packed_decode_input
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -178,94 +179,6 @@ BUNDLE_FILE_BYTES = 4 << 20        # files up to this size (~2 min of 16 kHz PCM
 BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (int16 samples of one bundle)
 BUNDLE_FILES = 256
 PACK_BATCHES = 8                   # recordings of fewer than this many batches of windows share forwards window by window
-
-
-class OpenRecording:
-    """A staged recording some of whose windows have not run yet (window packing, `pack_forward`)."""
-    __slots__ = ("i", "wav", "n", "n_win", "next_w", "parts")
-
-    def __init__(self, i: int, wav: torch.Tensor, n_win: int):
-        self.i, self.wav, self.n, self.n_win, self.next_w, self.parts = i, wav, int(wav.numel()), n_win, 0, []
-
-
-def pack_forward(engine, carry: deque, n_windows: int):
-    """One forward over the next n_windows windows of the recordings queued in `carry`, whatever recording they belong to:
-    the last windows of one recording, whole recordings, and the first windows of another may share it, so that every
-    forward but a run's last is FULL.  (A 600 s recording is 61 windows of 10 s: alone it leaves 3 of a 64-window batch
-    empty, and twenty-two of them fit 21 forwards.)  Windows are independent (a frame's logits do not depend on its
-    batch mates: tests/test_gpu_parity.py::test_full_size_batch64_10s_properties), so the rows are bit-identical to those
-    of the recording run alone.  The window plan per recording is vtc_infer_waveform's (step T * 320, zero-padded tail,
-    frames whose receptive field lies in the audio).  Enqueues only; returns (recordings completed by this forward, each with
-    its stitched logits in `parts`, in queue order; the forward's logits buffer)."""
-    W, T, step, nl = engine.window_samples, engine.frames_per_window, engine.step, engine.n_labels
-    cur = torch.cuda.current_stream(engine.device) if torch.device(engine.device).type == "cuda" else None
-    # plain Python lists, converted once: with thousands of 1-10 s recordings per second this runs per recording, under the GIL
-    # the reader threads and the row-building thread also need
-    segs, runs, start, valid, keep, dst = [], [], [], [], [], []
-    need, base, rows = n_windows, 0, 0
-    while need and carry:
-        o = carry[0]
-        w0, n = o.next_w, o.n
-        cnt = min(need, o.n_win - w0)
-        o.next_w = w0 + cnt
-        need -= cnt
-        if o.next_w == o.n_win:
-            carry.popleft()
-        a, b = w0 * step, min(n, (w0 + cnt - 1) * step + W)
-        if w0 == 0 and cur is not None:
-            o.wav.record_stream(cur)          # staged on a reader thread's stream
-        piece = o.wav if (a == 0 and b == n) else o.wav[a:b]
-        # pieces that follow each other in one device array (a bundle of short files, stage_bundle) are one run: no copy
-        # (adjacent blocks of different allocations do not count: the storage must be the same)
-        ptr, store = piece.data_ptr(), piece.untyped_storage().data_ptr()
-        if runs and runs[-1][2] == ptr and runs[-1][3] == store:
-            runs[-1][1] += b - a
-            runs[-1][2] += 4 * (b - a)
-        else:
-            runs.append([piece, b - a, ptr + 4 * (b - a), store])
-        off, r0 = base - a, rows
-        for w in range(w0, w0 + cnt):
-            s0 = w * step
-            rem = n - s0
-            k = (rem - RF_SIZE) // RF_STEP + 1
-            k = k if k < T else T
-            start.append(off + s0)
-            valid.append(rem if rem < W else W)
-            keep.append(k)
-            dst.append(rows)
-            rows += k
-        segs.append((o, r0, rows))
-        base += b - a
-    pieces = [r[0] if r[1] == r[0].numel() else torch.as_strided(r[0], (r[1],), (1,), r[0].storage_offset()) for r in runs]
-    # several runs: one copy of <= a batch of windows (41 MB at 64 x 10 s, ~20 us) in front of a 10 ms forward
-    arena = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
-    out = torch.empty((rows, nl), dtype=torch.float32, device=engine.device)
-    with torch.no_grad():
-        engine.forward_windows(arena, np.array(start, dtype=np.int64), np.array(valid, dtype=np.int32),
-                               np.array(dst, dtype=np.int64), np.array(keep, dtype=np.int32), out)
-    done = []
-    for o, r0, r1 in segs:
-        o.parts.append((out, r0, r1))         # sliced only when needed (packed_decode_input)
-        if o.next_w == o.n_win:
-            done.append(o)
-    return done, out
-
-
-def packed_decode_input(done: list, out: torch.Tensor):
-    """(logits, file_rows, n_samples) of the recordings a forward completed, in the form gpu_decode_launch takes: the rows of
-    the forward's own buffer when every recording lies inside it (they are consecutive: only a forward's first recording
-    can have earlier parts and only its last one can be incomplete), otherwise one concatenation."""
-    rows = np.zeros(len(done) + 1, dtype=np.int64)
-    single = True
-    for k, o in enumerate(done):
-        rows[k + 1] = rows[k] + sum(r1 - r0 for _, r0, r1 in o.parts)
-        single = single and len(o.parts) == 1
-    if single:
-        a = done[0].parts[0][1]
-        logits = out[a:a + int(rows[-1])]
-    else:
-        logits = torch.cat([t[r0:r1] for o in done for t, r0, r1 in o.parts])
-    return logits, rows, [o.n for o in done]
 
 
 def plan_reader_tasks(file_bytes: list, step: int, batch_size: int, bundle: bool = True) -> list:
