@@ -831,6 +831,11 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
                     add(tf, f"{cid}.wav", wav_bytes(np.zeros_like(x)))
                 add(tf, f"{cid}.json", b"{}")
                 k += 1
+                if t == 1 and c == 2:                           # a clip that cannot join a staging bundle, in the middle of one
+                    up = np.interp(np.arange(int(5.3 * 44100)) / 44100.0, np.arange(len(x)) / 16000.0, x).astype(np.float32)
+                    buf = io.BytesIO()
+                    wavfile.write(buf, 44100, np.clip(np.round(np.stack([up, 0.4 * up], axis=1) * 32768), -32768, 32767).astype(np.int16))
+                    add(tf, "uidC_0000.wav", buf.getvalue())
             if t == 0:
                 add(tf, "uidB_0000.flac", b"fLaC not decodable here")      # error, skipped
                 add(tf, "uidB_0001.json", b"{}")                            # no audio, error
@@ -840,7 +845,7 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
     raw = pq.read_table(out / "vtc_raw" / "shard_0.parquet")
     assert raw.schema.names == ["clip_id", "onset", "offset", "duration", "label"]
     rows = raw.to_pylist()
-    assert {r["clip_id"] for r in rows} <= set(audio)
+    assert {r["clip_id"] for r in rows} <= set(audio) | {"uidC_0000"}
     for cid, pcm in audio.items():
         ref = O.apply_model_on_waveform(weights, O.pcm_to_mono_float(pcm), 4.0)
         if not (ref.abs() > LOGIT_TOL).all():
@@ -852,9 +857,17 @@ def test_clips_caller_on_tar_shards(weights, tmp_path, monkeypatch):
         assert sorted(mine, key=key) == sorted(want, key=key), cid
     merged = pq.read_table(out / "vtc_merged" / "shard_0.parquet")
     assert merged.schema.names == raw.schema.names and merged.num_rows <= raw.num_rows
+    # one clip per forward, staged one by one (the reference's pattern): the same tables as packed forwards over bundled staging
+    import shutil
+    shutil.copytree(shard_dir, tmp_path / "output" / "ds1" / "shards")
+    (tmp_path / "manifests" / "ds1.csv").write_text("path\n")
+    clips.main("ds1", per_clip=True, **common)
+    for kind in ("vtc_raw", "vtc_merged"):
+        assert pq.read_table(tmp_path / "output" / "ds1" / "vtc_clips" / kind / "shard_0.parquet").to_pylist() == \
+            pq.read_table(out / kind / "shard_0.parquet").to_pylist(), kind
     # resume: nothing with segments is recomputed
     calls = []
-    monkeypatch.setattr(clips, "launch_group", lambda eng, group, *a, _f=clips.launch_group: (calls.append([c for c, _ in group]), _f(eng, group, *a))[1])
+    monkeypatch.setattr(clips, "pack_forward", lambda eng, carry, nw, _f=clips.pack_forward: (calls.append([o.i for o in carry]), _f(eng, carry, nw))[1])
     clips.main("ds", **common)
     done = {r["clip_id"] for r in rows}
     assert all(c not in done for g in calls for c in g)
