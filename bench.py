@@ -197,7 +197,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=120, help="windows of the bounded CPU-oracle sample (~15 s on 16 cores)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end CLI run (files -> parquet) at N=1")
-    ap.add_argument("--e2e-files", type=int, default=120, help="600 s PCM16 files of the end-to-end sample (20 audio-hours)")
+    ap.add_argument("--e2e-files", type=int, default=240, help="600 s PCM16 files of the end-to-end sample (40 audio-hours, a 2.5 s file loop)")
     ap.add_argument("--e2e-files-per-worker", type=int, default=480,
                     help="N > 1: 600 s files per CLI worker of the node-level end-to-end leg (80 audio-hours per worker)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")

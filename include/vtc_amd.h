@@ -210,6 +210,14 @@ int vtc_flac_decode(const void* data /*[host]*/, int64_t n_bytes, void* out /*[h
 int vtc_flac_decode_threads(const void* data /*[host]*/, int64_t n_bytes, void* out /*[host]*/, int32_t out_format,
                             int64_t out_cap, int64_t* n_out, int32_t n_threads);
 
+/* 4-bit IMA / DVI ADPCM blocks of a RIFF/WAVE file (format tag 0x0011; host side, no GPU work, no handle).  `.wav` is on the
+ * reference's manifest list (scripts/make_manifest.py:26-39) and the reference reads whatever torchcodec/ffmpeg accept inside
+ * segma (apply_model_on_audio, src/pipeline/vtc.py:236-243).  data = the 'data' chunk, block_align / samples_per_block = the
+ * 'fmt ' chunk's nBlockAlign / wSamplesPerBlock (0 = what a block holds); writes interleaved int16, at most out_cap
+ * inter-channel samples (the caller passes the 'fact' chunk's count, or blocks x samples_per_block), *n_out = those written. */
+int vtc_ima_adpcm_decode(const void* data /*[host]*/, int64_t n_bytes, int32_t n_channels, int32_t block_align,
+                         int32_t samples_per_block, int16_t* out /*[host]*/, int64_t out_cap, int64_t* n_out);
+
 /* Test hook: copy an intermediate activation of the LAST vtc_forward_windows call to the host as fp32.
  * stage: 0..6 conv layer outputs (B,L_i,512); 7 projection (B*T,768); 8 encoder input after pos-conv+LN;
  * 9+l output of transformer layer l.  Returns the element count, or a negative status. */

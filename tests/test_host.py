@@ -785,6 +785,70 @@ def test_g711_and_rf64_wav_files(tmp_path):
         assert audio.read_plain_wav_into(tmp_path / "big.wav", dst, 5) == 3000 and np.array_equal(dst[5:3005], x)
 
 
+def test_ima_adpcm_wav_against_audioop(tmp_path):
+    """4-bit IMA / DVI ADPCM in RIFF/WAVE (format tag 0x0011) through vtc_ima_adpcm_decode.  Pinned against an independent
+    implementation of the same codec, the standard library's audioop (Intel/DVI ADPCM): every block is encoded with
+    audioop.lin2adpcm from the state its header stores, and the library must give back exactly what audioop.adpcm2lin gives
+    for that block.  The WAVE layout differs from audioop's stream in two ways that the test spells out: codes sit LOW nibble
+    first (audioop: high first), and channels alternate in 4-byte groups of eight codes."""
+    audioop = pytest.importorskip("audioop")
+    import struct
+    from vtc_amd.audio import read_pcm
+
+    swap = bytes(((b & 15) << 4) | (b >> 4) for b in range(256))
+
+    def ima_wav(path, pcm, sr, align):
+        n, ch = pcm.shape
+        spb = 1 + (align - 4 * ch) // (4 * ch) * 8
+        blocks, want, index = [], np.zeros_like(pcm), [0] * ch
+        for a in range(0, n, spb):
+            part = pcm[a:a + spb]
+            if len(part) < spb:
+                part = np.concatenate([part, np.zeros((spb - len(part), ch), np.int16)])
+            head, codes = b"", []
+            for c in range(ch):
+                first = int(part[0, c])
+                head += struct.pack("<hBB", first, index[c], 0)
+                enc, state = audioop.lin2adpcm(part[1:, c].astype("<i2").tobytes(), 2, (first, index[c]))
+                dec, _ = audioop.adpcm2lin(enc, 2, (first, index[c]))
+                blk = np.concatenate([[first], np.frombuffer(dec, "<i2")])
+                want[a:a + spb, c] = blk[:len(pcm[a:a + spb])]
+                index[c] = state[1]
+                codes.append(enc.translate(swap))
+            body = b"".join(codes[c][g * 4:g * 4 + 4] for g in range((spb - 1) // 8) for c in range(ch))
+            blocks.append(head + body)
+        data = b"".join(blocks)
+        fmt = struct.pack("<HHIIHHHH", 0x11, ch, sr, sr * align // spb, align, 4, 2, spb)
+        fact = struct.pack("<I", n)
+        riff = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact + \
+            b"data" + struct.pack("<I", len(data)) + data
+        path.write_bytes(b"RIFF" + struct.pack("<I", len(riff)) + riff)
+        return want
+
+    rng = np.random.default_rng(12)
+    t = np.arange(16000 * 3) / 16000.0
+    sig = 0.6 * np.sin(2 * np.pi * 220 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 1.5 * t)) + 0.05 * rng.standard_normal(len(t))
+    sig[5000:5200] = 1.2                      # clipping drives the predictor into its clamp
+    mono = np.clip(np.round(sig * 32767), -32768, 32767).astype(np.int16)[:, None]
+    stereo = np.stack([mono[:, 0], np.roll(mono[:, 0], 777) // 3], axis=1)[: 16000 * 2 + 123]
+    for name, pcm, sr, align in (("m256.wav", mono, 16000, 256), ("m1024.wav", mono[:10001], 8000, 1024),
+                                 ("s512.wav", stereo, 22050, 512), ("s2048.wav", stereo, 44100, 2048)):
+        want = ima_wav(tmp_path / name, pcm, sr, align)
+        got, got_sr = read_pcm(tmp_path / name)
+        got = got.reshape(len(got), -1)
+        assert got_sr == sr and got.dtype == np.int16 and got.shape == pcm.shape, name
+        assert np.array_equal(got, want), name
+        err = np.abs(got.astype(np.int32) - pcm.astype(np.int32))
+        assert np.median(err) < 400, name      # and it is the signal, not just the same codes
+    # malformed: a step index above 88 in a block header is an error, not a read past the table
+    raw = bytearray((tmp_path / "m256.wav").read_bytes())
+    at = raw.index(b"data") + 8
+    raw[at + 2] = 120
+    (tmp_path / "bad.wav").write_bytes(bytes(raw))
+    with pytest.raises(Exception, match="step index"):
+        read_pcm(tmp_path / "bad.wav")
+
+
 def test_columnar_segments_and_meta_equal_the_scalar_forms():
     """The CLI gathers segments as column blocks (core.intervals.intervals_to_columns, metadata.vtc_meta_row_columns,
     utils.segments_table_from_blocks); they must give exactly the rows of the scalar mirror of the reference

@@ -2,7 +2,7 @@
 
 The reference leaves decoding to segma (torchaudio/torchcodec, requirements.txt:393-394); the rule for
 non-16 kHz or multi-channel input is unpinned.  Here: WAV (PCM 8/16/24/32, float, G.711 A-law /
-mu-law, RF64 / BW64 headers; own RIFF parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
+mu-law, 4-bit IMA ADPCM, RF64 / BW64 headers; own RIFF parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
 other rates are resampled with torchaudio's windowed-sinc polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
 The lossy formats of scripts/make_manifest.py:26-39 (mp3, ogg, opus, m4a, aac, wma) need codecs that are not available
 offline; they raise, which the pipeline turns into an error row.
@@ -188,6 +188,49 @@ def decode_flac(data, verify_md5: bool = False, n_threads: int | None = None):
     return (out[:, 0] if ch.value == 1 else out), int(sr.value)
 
 
+def decode_ima_adpcm_wav(data):
+    """RIFF/WAVE with 4-bit IMA / DVI ADPCM (format tag 0x0011) held in memory -> (int16 samples (n,) or (n, channels),
+    sample_rate), or None when the file is something else.  The blocks are decoded by libvtc_amd.so (vtc_ima_adpcm_decode,
+    outside the GIL); the 'fact' chunk, when present, gives the true length (the last block is padded)."""
+    import ctypes as C
+    import struct
+
+    from . import lib as L
+
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
+    if buf.size < 12 or bytes(buf[:4]) != b"RIFF" or bytes(buf[8:12]) != b"WAVE":
+        return None
+    pos, fmt, fact, chunk = 12, None, None, None
+    while pos + 8 <= buf.size:
+        cid, size = bytes(buf[pos:pos + 4]), struct.unpack("<I", bytes(buf[pos + 4:pos + 8]))[0]
+        body = pos + 8
+        if cid == b"fmt " and size >= 16:
+            tag, ch, sr, _, align, bits = struct.unpack("<HHIIHH", bytes(buf[body:body + 16]))
+            spb = struct.unpack("<H", bytes(buf[body + 18:body + 20]))[0] if size >= 20 else 0
+            fmt = (tag, ch, sr, align, bits, spb)
+        elif cid == b"fact" and size >= 4:
+            fact = struct.unpack("<I", bytes(buf[body:body + 4]))[0]
+        elif cid == b"data":
+            chunk = (body, min(size, buf.size - body) if size not in (0, 0xFFFFFFFF) else buf.size - body)
+            break
+        pos = body + size + (size & 1)
+    if fmt is None or chunk is None or fmt[0] != 0x11:
+        return None
+    tag, ch, sr, align, bits, spb = fmt
+    if bits != 4 or ch < 1 or align < 4 * ch:
+        raise ValueError(f"IMA ADPCM WAV: unsupported layout ({bits} bits per sample, {ch} channels, blocks of {align} bytes)")
+    full = 1 + (align - 4 * ch) // (4 * ch) * 8
+    cap = -(-chunk[1] // align) * (spb or full)
+    if fact is not None and 0 < fact < cap:
+        cap = fact
+    out = np.empty((cap, ch), dtype=np.int16)
+    got = C.c_int64()
+    L.check(L.load().vtc_ima_adpcm_decode(C.c_void_p(buf.ctypes.data + chunk[0]), C.c_int64(chunk[1]), ch, align, spb,
+                                          C.c_void_p(out.ctypes.data), cap, C.byref(got)))
+    out = out[:got.value]
+    return (out[:, 0] if ch == 1 else out), int(sr)
+
+
 def decode_aiff(data):
     """AIFF / AIFF-C with uncompressed PCM ('NONE', 'twos', 'sowt', 'fl32'/'FL32') or G.711 ('ulaw', 'alaw') ->
     (samples, sample_rate)."""
@@ -267,6 +310,9 @@ def read_pcm(path):
     fast = _fast_wav(path)
     if fast is not None:
         return fast
+    adpcm = decode_ima_adpcm_wav(_file_bytes(path))
+    if adpcm is not None:
+        return adpcm
     from scipy.io import wavfile
 
     try:

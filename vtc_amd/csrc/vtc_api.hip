@@ -20,6 +20,7 @@
 #include "common.hip.h"
 #include "decode_kernels.hip.h"
 #include "encoder_kernels.hip.h"
+#include "adpcm_decode.h"
 #include "flac_decode.h"
 #include "gemm.hip.h"
 #include "gemm256.hip.h"
@@ -1357,6 +1358,16 @@ int vtc_flac_decode_threads(const void* data, int64_t n_bytes, void* out, int32_
                                     : flac::decode((const uint8_t*)data, n_bytes, out, out_format, out_cap, si, err);
   if (got == -2) return fail(nullptr, VTC_ERR_CAPACITY, "%s", err.msg.c_str());
   if (got < 0) return fail(nullptr, VTC_ERR_ARG, "%s", err.msg.c_str());
+  *n_out = got;
+  return VTC_OK;
+}
+
+int vtc_ima_adpcm_decode(const void* data, int64_t n_bytes, int32_t n_channels, int32_t block_align, int32_t samples_per_block,
+                         int16_t* out, int64_t out_cap, int64_t* n_out) {
+  if (!data || n_bytes < 0 || !out || out_cap < 0 || !n_out) return fail(nullptr, VTC_ERR_ARG, "null argument");
+  const char* why = "";
+  const int64_t got = adpcm::decode_ima((const uint8_t*)data, n_bytes, n_channels, block_align, samples_per_block, out, out_cap, &why);
+  if (got < 0) return fail(nullptr, VTC_ERR_ARG, "%s", why);
   *n_out = got;
   return VTC_OK;
 }

@@ -80,6 +80,7 @@ SYMBOLS = {
     "vtc_flac_info": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i64p, C.c_void_p]),
     "vtc_flac_decode": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, _i64p]),
     "vtc_flac_decode_threads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, _i64p, C.c_int32]),
+    "vtc_ima_adpcm_decode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, _i64p]),
     "vtc_debug_stage": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.c_int64]),
     "vtc_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtc_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
