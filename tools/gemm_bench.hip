@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
   };
   size_t maxA = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) {
+    if (!strstr(s.name, only)) continue;     // buffers sized for the shapes that will run (start-up is host-side random data)
     size_t a = s.batch_stride ? (size_t)(s.M / s.rows_per_batch) * s.batch_stride + s.K : (size_t)s.M * s.K;
     maxA = std::max(maxA, a); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N);
   }
