@@ -11,6 +11,8 @@ configs[3] (a day-long recording) at their stated shape, through the CLI, checke
   * two shards (launcher, one worker process per shard) together equal the single-process run;
   * a run killed with SIGKILL resumes from its last flush, redoes only what was not flushed, and ends with the same tables.
 
+A second test runs BASELINE.json configs[1] at its stated size (100 audio-hours = 600 files x 600 s, 10 s windows, batch 64).
+
 The end-to-end rate of each leg goes to gpurun_out/c5_c4_e2e.json (copied to profiles/ by hand): wall time of the whole
 call (model construction, first launches, final parquet writes included) and, separately, the steady-state rate of the file
 loop as the CLI logs it (logs/benchmarks.jsonl: total_audio_seconds / wall_seconds, which starts after model construction).
@@ -196,4 +198,75 @@ def test_c5_skewed_manifest_and_c4_daylong_through_the_cli(tmp_path, monkeypatch
     dst = ROOT / "gpurun_out"
     dst.mkdir(exist_ok=True)
     (dst / "c5_c4_e2e.json").write_text(json.dumps(record, indent=1) + "\n")
+    print(json.dumps(record))
+
+
+def test_c2_hundred_hours_identical_content_gives_identical_rows(tmp_path, monkeypatch):
+    """BASELINE.json configs[1] at its stated size through the CLI: 100 audio-hours = 600 files x 600 s, 10 s windows, batch 64.
+    The files are hard links of five distinct recordings (599.0 ... 600.4 s, so the copies of one recording start at every
+    position of the packed forwards: a 600 s file is 61 windows of a 64-window batch).  Properties, all size-independent:
+    one meta row per file in manifest order and no error row; every copy of a recording has exactly the rows and the meta
+    values of its first copy, whatever forwards its windows rode in (window packing, determinism: reference
+    tests/test_reproducibility.py:212 expects torch.equal run to run); and the first copy's rows are those of the recording
+    run alone through the engine.  The rate goes to gpurun_out/c2_e2e.json."""
+    from vtc_amd.engine import VtcEngine
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+    n_files, lens = 600, [600.0, 599.0, 600.4, 599.73, 600.0]
+    pcm = [np.clip(np.round(synth.synth_audio(d, seed=1000 + k) * 32768.0), -32768, 32767).astype(np.int16) for k, d in enumerate(lens)]
+    names, kind_of = [], []
+    for i in range(n_files):
+        k = (i * 7 + i // 11) % len(lens)
+        p = tmp_path / "audio" / f"f{i:04d}.wav"
+        if i < len(lens):
+            k = i
+            _write_wav16(p, pcm[k])
+        else:
+            os.link(tmp_path / "audio" / f"f{k:04d}.wav", p)
+        names.append(str(p))
+        kind_of.append(k)
+    (tmp_path / "manifests" / "c2.csv").write_text("path\n" + "\n".join(names) + "\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 10.0\n")
+    hours = sum(len(pcm[k]) for k in kind_of) / 16000 / 3600
+    assert 99.5 < hours < 100.5
+    t0 = time.time()
+    cli.main("c2", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=64, flush_seconds=0.0)
+    wall = time.time() - t0
+    stats = dict(cli.PACK_STATS)
+    log = json.loads((tmp_path / "logs" / "benchmarks.jsonl").read_text().strip().splitlines()[-1])
+    out = tmp_path / "output" / "c2"
+    meta, raw = _tables(out, "vtc_meta"), _tables(out, "vtc_raw")
+    uids = [f"f{i:04d}" for i in range(n_files)]
+    assert [r["uid"] for r in meta] == uids and all(r["error"] == "" for r in meta)
+    by_uid = {}
+    for r in raw:
+        by_uid.setdefault(r["uid"], []).append((r["onset"], r["offset"], r["duration"], r["label"]))
+    keys = ("vtc_speech_dur", "vtc_n_segments", "vtc_label_counts", "vtc_max_sigmoid", "vtc_mean_sigmoid")
+    for i in range(n_files):
+        first = kind_of[i]
+        assert by_uid[uids[i]] == by_uid[uids[first]], (i, first)
+        assert all(meta[i][k] == meta[first][k] for k in keys), (i, first)
+    assert all(len(by_uid[uids[k]]) > 500 for k in range(len(lens)))
+    # 36,600 windows in full forwards of 64: nothing but the last forward (and a flush when the readers lag) is partial
+    assert stats["windows"] == sum(-(-(len(pcm[k]) - 399) // (499 * 320)) for k in kind_of)
+    assert stats["windows"] / stats["forwards"] > 62.0, stats
+    eng = VtcEngine(synth.make_weights(seed=0), n_labels=4, chunk_duration_s=10.0, max_batch=64, device=0)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    for k in range(len(lens)):
+        wav = torch.from_numpy(pcm[k]).cuda().to(torch.float32) * (1.0 / 32768.0)
+        s_, e_, l_, _, _ = eng.decode(eng.infer_waveform(wav, batch_size=64).contiguous(), lo, hi)
+        want = O.intervals_to_segments([(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s_, e_, l_)], uids[k])
+        assert by_uid[uids[k]] == [(r["onset"], r["offset"], r["duration"], r["label"]) for r in want], k
+    eng.close()
+    record = {"what": "BASELINE configs[1] at its stated size through the vtc_amd.pipeline.vtc CLI: 600 PCM16 WAV files x 600 s on local disk "
+                      "-> parquet, 10 s windows, batch 64, one MI355X, one process", "files": n_files, "audio_hours": round(hours, 3),
+              "wall_s_with_model_construction": round(wall, 2), "file_loop_s": round(log["wall_seconds"], 2),
+              "audio_hours_per_s_steady_state": round(log["total_audio_seconds"] / 3600.0 / log["wall_seconds"], 3),
+              "packed_forwards": stats["forwards"], "packed_windows": stats["windows"], "raw_segments": len(raw),
+              "stage_seconds": {k: round(v, 2) for k, v in cli.STAGE_SECONDS.items()}}
+    dst = ROOT / "gpurun_out"
+    dst.mkdir(exist_ok=True)
+    (dst / "c2_e2e.json").write_text(json.dumps(record, indent=1) + "\n")
     print(json.dumps(record))
