@@ -1144,6 +1144,26 @@ def test_cli_window_packing_equals_whole_recordings_per_forward(tmp_path, monkey
         a = torch.load(tmp_path / "output" / "pk" / "logits" / f"{uid}-logits_dict_t.pt", weights_only=True)
         b = torch.load(tmp_path / "output" / "np" / "logits" / f"{uid}-logits_dict_t.pt", weights_only=True)
         assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a), uid
+    # a packed forward that fails (here: the 3rd and the 7th raise before anything is enqueued) sends every recording it
+    # touched, cut ones included, through the single-recording path: same tables, no error rows beyond the two expected
+    monkeypatch.delenv("VTC_NO_PACK")
+    (tmp_path / "manifests" / "pf.csv").write_text("path\n" + "\n".join(names) + "\n")
+    calls = {"n": 0}
+    real = cli.pack_forward
+
+    def flaky(engine, carry, n_windows):
+        calls["n"] += 1
+        if calls["n"] in (3, 7):
+            raise RuntimeError("injected failure of a packed forward")
+        return real(engine, carry, n_windows)
+
+    monkeypatch.setattr(cli, "pack_forward", flaky)
+    cli.main("pf", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=16, prefetch=3)
+    assert calls["n"] > 7
+    for kind in ("vtc_meta", "vtc_raw", "vtc_merged"):
+        a = pq.read_table(tmp_path / "output" / "pf" / kind / "shard_0.parquet")
+        b = pq.read_table(tmp_path / "output" / "np" / kind / "shard_0.parquet")
+        assert json.dumps(a.to_pylist(), sort_keys=True) == json.dumps(b.to_pylist(), sort_keys=True), kind
 
 
 def test_cli_reruns_files_that_overflow_fp16_with_bf16_storage(weights, tmp_path, monkeypatch):
