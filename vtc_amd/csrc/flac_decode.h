@@ -245,6 +245,13 @@ inline bool read_residual(BitReader& br, int64_t* out, int blocksize, int order,
   return true;
 }
 
+// Prediction arithmetic wraps (unsigned): a valid stream stays far inside 64 bits (<= 33-bit samples x 15-bit coefficients x
+// 32 taps), a damaged one whose frame CRC has not been reached yet may not, and signed overflow would be undefined behaviour
+// (found by tools/fuzz_decoders.cpp under UBSan).  Same instructions as the signed form.
+inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+inline int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+
 // s[i] += (sum_j coef[j] * s[i-1-j]) >> shift, the order known at compile time so the taps unroll
 template <int ORDER>
 inline void lpc_restore_n(int64_t* s, int n, const int32_t* coef, int shift) {
@@ -253,8 +260,8 @@ inline void lpc_restore_n(int64_t* s, int n, const int32_t* coef, int shift) {
   for (int i = ORDER; i < n; ++i) {
     int64_t acc = 0;
 #pragma GCC unroll 32
-    for (int j = 0; j < ORDER; ++j) acc += c[j] * s[i - 1 - j];
-    s[i] += acc >> shift;
+    for (int j = 0; j < ORDER; ++j) acc = wadd(acc, wmul(c[j], s[i - 1 - j]));
+    s[i] = wadd(s[i], acc >> shift);
   }
 }
 template <int... I>
@@ -295,16 +302,17 @@ inline bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps, Err
     if (!read_residual(br, s, blocksize, order, err)) return false;
     switch (order) {
       case 1:
-        for (int i = 1; i < blocksize; ++i) s[i] += s[i - 1];
+        for (int i = 1; i < blocksize; ++i) s[i] = wadd(s[i], s[i - 1]);
         break;
       case 2:
-        for (int i = 2; i < blocksize; ++i) s[i] += 2 * s[i - 1] - s[i - 2];
+        for (int i = 2; i < blocksize; ++i) s[i] = wadd(s[i], wsub(wmul(2, s[i - 1]), s[i - 2]));
         break;
       case 3:
-        for (int i = 3; i < blocksize; ++i) s[i] += 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3];
+        for (int i = 3; i < blocksize; ++i) s[i] = wadd(s[i], wadd(wsub(wmul(3, s[i - 1]), wmul(3, s[i - 2])), s[i - 3]));
         break;
       case 4:
-        for (int i = 4; i < blocksize; ++i) s[i] += 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4];
+        for (int i = 4; i < blocksize; ++i)
+          s[i] = wadd(s[i], wsub(wadd(wsub(wmul(4, s[i - 1]), wmul(6, s[i - 2])), wmul(4, s[i - 3])), s[i - 4]));
         break;
       default:
         break;
@@ -415,7 +423,11 @@ inline bool decode_frame(const uint8_t* d, int64_t n, int64_t o, const StreamInf
     err.msg = "truncated FLAC frame header";
     return false;
   }
+#ifdef VTC_FLAC_FUZZ_SKIP_CRC   // tools/fuzz_decoders.cpp only: lets damaged frames reach the subframe parsers
+  if ((void)br.bits(8), false) {
+#else
   if (crc8(d + o, hdr_end) != br.bits(8)) {
+#endif
     snprintf(b, sizeof b, "FLAC frame header CRC mismatch at byte %lld", (long long)o);
     err.msg = b;
     return false;
@@ -452,7 +464,11 @@ inline bool decode_frame(const uint8_t* d, int64_t n, int64_t o, const StreamInf
     err.msg = "truncated FLAC frame (no CRC)";
     return false;
   }
+#ifdef VTC_FLAC_FUZZ_SKIP_CRC
+  if (false) {
+#else
   if (crc16(d + o, body_end) != (uint16_t)((body_end[0] << 8) | body_end[1])) {
+#endif
     snprintf(b, sizeof b, "FLAC frame CRC mismatch at byte %lld", (long long)o);
     err.msg = b;
     return false;
@@ -460,14 +476,14 @@ inline bool decode_frame(const uint8_t* d, int64_t n, int64_t o, const StreamInf
   int64_t* c0 = block;
   int64_t* c1 = block + 65536;
   if (ch_code == 8) {
-    for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+    for (int i = 0; i < blocksize; ++i) c1[i] = wsub(c0[i], c1[i]);
   } else if (ch_code == 9) {
-    for (int i = 0; i < blocksize; ++i) c0[i] = c0[i] + c1[i];
+    for (int i = 0; i < blocksize; ++i) c0[i] = wadd(c0[i], c1[i]);
   } else if (ch_code == 10) {
     for (int i = 0; i < blocksize; ++i) {
       int64_t side = c1[i], mid = (int64_t)((uint64_t)c0[i] << 1) | (side & 1);
-      c0[i] = (mid + side) >> 1;
-      c1[i] = (mid - side) >> 1;
+      c0[i] = wadd(mid, side) >> 1;
+      c1[i] = wsub(mid, side) >> 1;
     }
   }
   fi.blocksize = blocksize;
