@@ -849,6 +849,66 @@ def test_ima_adpcm_wav_against_audioop(tmp_path):
         read_pcm(tmp_path / "bad.wav")
 
 
+def test_damaged_audio_files_raise_and_never_hang(tmp_path):
+    """A manifest of thousands of files holds damaged ones.  read_pcm on mutated WAV (PCM16, stereo 44.1 kHz, 8-bit), AIFF and
+    FLAC files (bit flips, random bytes, truncation, insertions, 32-bit size fields set to extreme values) must either return
+    int16 / float32 samples or raise an Exception (which the CLI turns into an error row, reference vtc.py:245-249), quickly,
+    whatever the header claims (a size field of 4 GB must not allocate 4 GB)."""
+    import struct
+    import time
+    import warnings
+    from scipy.io import wavfile
+    from oracle import flac_codec as FL
+    from vtc_amd.audio import read_pcm, write_wav
+
+    x = (0.3 * np.sin(np.arange(8000) * 0.05)).astype(np.float32)
+    seeds = {}
+    write_wav(tmp_path / "a.wav", x)
+    wavfile.write(tmp_path / "b.wav", 44100, np.stack([x, x], 1))
+    wavfile.write(tmp_path / "c.wav", 8000, (x * 127 + 128).astype(np.uint8))
+    pcm_be = (x * 32767).astype(">i2").tobytes()
+    comm = struct.pack(">hIh", 1, len(x), 16) + b"\x40\x0c\xfa\x00\x00\x00\x00\x00\x00\x00"      # 16 kHz as 80-bit extended
+    body = b"AIFF" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">III", len(pcm_be) + 8, 0, 0) + pcm_be
+    (tmp_path / "d.aiff").write_bytes(b"FORM" + struct.pack(">I", len(body)) + body)
+    (tmp_path / "e.flac").write_bytes(FL.encode((x * 32767).astype(np.int64), 16000))
+    for n in ("a.wav", "b.wav", "c.wav", "d.aiff", "e.flac"):
+        seeds[n] = (tmp_path / n).read_bytes()
+        got, sr = read_pcm(tmp_path / n)                          # the seeds themselves read
+        assert len(got) == len(x) and sr in (16000, 44100, 8000)
+    rng = np.random.default_rng(0)
+    outcomes = {"ok": 0}
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(3000):
+            name = list(seeds)[it % len(seeds)]
+            d = bytearray(seeds[name])
+            for _ in range(int(rng.integers(1, 5))):
+                at = int(rng.integers(len(d))) if rng.random() < 0.5 else int(rng.integers(min(len(d), 80)))
+                op = int(rng.integers(5))
+                if op == 0:
+                    d[at] ^= 1 << int(rng.integers(8))
+                elif op == 1:
+                    d[at] = int(rng.integers(256))
+                elif op == 2:
+                    del d[at:]
+                elif op == 3:
+                    d[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+                else:
+                    d[at:at + 4] = struct.pack("<I", int(rng.choice([0, 1, 0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, len(d) * 3])))
+                if not d:
+                    d = bytearray(b"\0")
+            p = tmp_path / ("m" + Path(name).suffix)
+            p.write_bytes(bytes(d))
+            try:
+                got, sr = read_pcm(p)
+                assert got.dtype in (np.int16, np.float32) and got.nbytes < (64 << 20)
+                outcomes["ok"] += 1
+            except Exception as e:       # anything that is an Exception becomes an error row; a crash or a hang would not get here
+                outcomes[type(e).__name__] = outcomes.get(type(e).__name__, 0) + 1
+    assert time.time() - t0 < 120 and outcomes["ok"] > 300 and sum(outcomes.values()) == 3000, outcomes
+
+
 def test_columnar_segments_and_meta_equal_the_scalar_forms():
     """The CLI gathers segments as column blocks (core.intervals.intervals_to_columns, metadata.vtc_meta_row_columns,
     utils.segments_table_from_blocks); they must give exactly the rows of the scalar mirror of the reference
