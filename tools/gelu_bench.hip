@@ -62,8 +62,8 @@ __device__ const float2* g_tab;
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(float* out, int iters, long long* cyc) {
-  __shared__ float2 tab[(MODE >= 4) ? kGeluNodes : 1];
-  if (MODE >= 4) {
+  __shared__ float2 tab[(MODE >= 4 && MODE != 6) ? kGeluNodes : 1];
+  if (MODE >= 4 && MODE != 6) {
     for (int i = threadIdx.x; i < kGeluNodes; i += 512) tab[i] = g_tab[i];
     __syncthreads();
   }
@@ -86,6 +86,13 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, long long* cy
       for (int i = 0; i < 16; i += 2) {
         f32x2 r = MODE == 4 ? gelu_tab_pk<true>(f32x2{v[i], v[i + 1]}, (const char*)tab) : gelu_tab_pk<false>(f32x2{v[i], v[i + 1]}, (const char*)tab);
         v[i] = r[0] * 3.1f - 1.1f; v[i + 1] = r[1] * 2.3f - 0.7f;      // keeps the lanes on different, moving table entries
+      }
+    } else if (MODE >= 7 && MODE <= 9) {   // mixed: MODE 7: 8 of 16 by table, MODE 8: 6 of 16, MODE 9: 4 of 16; the rest by exp2 + rcp
+      constexpr int NT = MODE == 7 ? 8 : MODE == 8 ? 6 : 4;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 r = i < NT ? gelu_tab_pk<true>(f32x2{v[i], v[i + 1]}, (const char*)tab) : gelu_pk(f32x2{v[i], v[i + 1]});
+        v[i] = r[0] * 3.1f - 1.1f; v[i + 1] = r[1] * 2.3f - 0.7f;
       }
     } else if (MODE == 6) {       // packed form with the same feedback as the table modes (like for like)
 #pragma unroll
@@ -132,6 +139,7 @@ int main() {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &tab_d, sizeof tab_d));
   run<0>("gelu_f scalar", out, cyc); run<1>("gelu packed fp32", out, cyc); run<2>("exp2 + add + rcp", out, cyc); run<3>("8 fma", out, cyc);
   run<6>("gelu packed, moving inputs", out, cyc); run<4>("gelu table (sat modifier)", out, cyc); run<5>("gelu table (med3)", out, cyc);
+  run<7>("mixed: 8 of 16 by table", out, cyc); run<8>("mixed: 6 of 16 by table", out, cyc); run<9>("mixed: 4 of 16 by table", out, cyc);
   // accuracy of the table forms against erf, |x| <= 8 and a few far values
   const int n = 1 << 22;
   std::vector<float> hx(n), hy(n);
