@@ -107,12 +107,12 @@ def test_c5_skewed_manifest_and_c4_daylong_through_the_cli(tmp_path, monkeypatch
     short = {uids[k] for k in range(N_FILES) if n_samples[k] < 400}
     assert len(short) == 2
     record = {"files": N_FILES, "audio_hours": round(float(hours), 3), "cap_hours": CAP_HOURS, "chunk_duration_s": 4.0,
-              "batch_size": 128, "longest_file_s": DAYLONG_S, "files_of_an_hour_or_more": int((n_samples >= 3600 * 16000).sum()),
+              "batch_size": 164, "longest_file_s": DAYLONG_S, "files_of_an_hour_or_more": int((n_samples >= 3600 * 16000).sum()),
               "files_under_10_s": int((n_samples < 10 * 16000).sum()), "median_file_s": float(np.median(n_samples) / 16000), "what": "vtc_amd.pipeline.vtc CLI, PCM16 WAV files on local disk -> parquet, one MI355X"}
 
     # ---- leg 1: one process, one shard
     t0 = time.time()
-    cli.main("c5", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=128, flush_seconds=0.0)
+    cli.main("c5", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=164, flush_seconds=0.0)
     wall = time.time() - t0
     log = json.loads((tmp_path / "logs" / "benchmarks.jsonl").read_text().strip().splitlines()[-1])
     record["single_process"] = {"wall_s": round(wall, 2), "audio_hours_per_s_with_model_construction": round(hours / wall, 3),
@@ -156,7 +156,7 @@ def test_c5_skewed_manifest_and_c4_daylong_through_the_cli(tmp_path, monkeypatch
 
     # ---- leg 2: two shards, one worker process each (both on the one GPU of the test box)
     env = dict(os.environ, PYTHONPATH=str(ROOT))
-    args = ["--config", str(tmp_path / "cfg.yml"), "--checkpoint", "synthetic:0", "--batch_size", "128"]
+    args = ["--config", str(tmp_path / "cfg.yml"), "--checkpoint", "synthetic:0", "--batch_size", "164"]
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "vtc_amd.launcher", "c5two", "--gpus", "2", "--devices", "0,0", "--"] + args + ["--balance"],
                        env=env, capture_output=True, text=True, timeout=600)

@@ -588,6 +588,13 @@ def test_batch_size_recommendation():
     from vtc_amd.pipeline.vtc import recommend_vtc_batch_size as rec
     assert [rec(v) for v in (288, 80, 79, 48, 40, 32, 24, 16, 8)] == [512, 512, 256, 256, 192, 192, 128, 64, 32]
     assert rec(288, 10.0) == 208 and rec(288, 4.0) == 512 and rec(24, 10.0) == 48 and rec(8, 30.0) == 16
+    # trimmed to whole rounds of 256-row GEMM tiles over 256 CUs (never above the ladder's value, never below 80 % of it)
+    from vtc_amd.pipeline.vtc import tile_friendly_batch as fit
+    assert fit(512, 4.0) == 491 and fit(208, 10.0) == 196 and fit(64, 10.0) == 64 and fit(128, 4.0) == 128
+    for cap, chunk in ((512, 4.0), (256, 4.0), (192, 4.0), (208, 10.0), (96, 15.0), (7, 4.0), (33, 2.0)):
+        assert max(1, int(cap * 0.8)) <= fit(cap, chunk) <= cap
+    # 491 windows of 4 s: 97,709 frames = 382 row tiles; x 4 column tiles = 1,528 tiles = 5.97 rounds, x 12 = 17.9 rounds
+    assert -(-491 * 199 // 256) == 382
 
 
 def test_launcher_cpu_slices_and_thread_budget():

@@ -30,7 +30,7 @@ def main() -> None:
     ap.add_argument("--min_s", type=float, default=3.0)
     ap.add_argument("--max_s", type=float, default=30.0)
     ap.add_argument("--chunk", type=float, default=4.0)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=164)
     args = ap.parse_args()
     from scipy.io import wavfile
 

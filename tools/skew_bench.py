@@ -29,7 +29,7 @@ def main() -> None:
     ap.add_argument("--min-seconds", type=float, default=1.0)
     ap.add_argument("--max-seconds", type=float, default=30.0)
     ap.add_argument("--chunk", type=float, default=4.0)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=164)
     ap.add_argument("--prefetch", type=int, default=4)
     ap.add_argument("--no_group", action="store_true")
     args = ap.parse_args()

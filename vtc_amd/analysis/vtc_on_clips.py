@@ -40,7 +40,7 @@ import torch
 from ..audio import decode_flac, to_float32
 from ..core.intervals import intervals_to_columns
 from ..engine import RF_SIZE
-from ..packing import OpenRecording, pack_forward, packed_decode_input
+from ..packing import OpenRecording, pack_forward, packed_decode_input, tile_friendly_batch
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -132,7 +132,7 @@ def run_group(engine, group, lo, hi, labels, batch_size):
 
 
 def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str = "VTC-2.0/model/best.ckpt",
-         threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 128,
+         threshold: float = 0.5, min_duration_on_s: float = 0.1, min_duration_off_s: float = 0.3, batch_size: int = 0,
          device: str = "cuda", array_id: int | None = None, array_count: int | None = None,
          per_clip: bool = False) -> None:
     set_seeds(42)
@@ -180,6 +180,8 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
     dev_index = torch.cuda.current_device()
     model.to(torch.device("cuda", dev_index))
     chunk_duration_s = model_config.audio.chunk_duration_s
+    if batch_size <= 0:
+        batch_size = tile_friendly_batch(max(16, int(round(164 * 4.0 / float(chunk_duration_s)))), float(chunk_duration_s))
     engine = model.engine(chunk_duration_s, batch_size)
     labels = l_encoder.labels
     lo, hi = logit_bounds({l: {"lower_bound": threshold, "upper_bound": 1.0} for l in labels}, labels)
@@ -420,7 +422,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--threshold", type=float, default=0.5, help="Sigmoid threshold (default: 0.5)")
     p.add_argument("--min_duration_on_s", type=float, default=0.1, help="Remove segments shorter than this (0.1 s)")
     p.add_argument("--min_duration_off_s", type=float, default=0.3, help="Merge same-label gaps smaller than this (0.3 s)")
-    p.add_argument("--batch_size", type=int, default=128, help="Windows per forward pass, shared by the clips of a batch")
+    p.add_argument("--batch_size", type=int, default=0, help="Windows per forward pass, shared by the clips of a batch; 0 = 164 windows of 4 s, scaled by the window length and trimmed to whole rounds of GEMM tiles (packing.py::tile_friendly_batch)")
     p.add_argument("--device", default="cuda", choices=["cuda", "cpu", "mps"], help="Only 'cuda' (ROCm) is supported")
     p.add_argument("--array_id", type=int, help="Shard index (SLURM array task ID or launcher rank)")
     p.add_argument("--array_count", type=int, help="Number of shards")

@@ -1,4 +1,5 @@
-"""Window packing: recordings share forward passes window by window (host logic above vtc_forward_windows).
+"""Window packing: recordings share forward passes window by window (host logic above vtc_forward_windows), and the batch
+size at which those forwards fill whole rounds of GEMM tiles.
 
 Used by the file loop (pipeline/vtc.py) and by the clips caller (analysis/vtc_on_clips.py).  The reference runs one recording
 per `apply_model_on_audio` call (src/pipeline/vtc.py:236-243); its window plan per recording is kept exactly
@@ -101,3 +102,38 @@ def packed_decode_input(done: list, out: torch.Tensor):
     else:
         logits = torch.cat([t[r0:r1] for o in done for t, r0, r1 in o.parts])
     return logits, rows, [o.n for o in done]
+
+
+def tile_friendly_batch(max_batch: int, chunk_duration_s: float, n_cus: int = 256) -> int:
+    """The batch size <= max_batch (and >= 80 % of it) at which the persistent GEMMs waste the least of their last round of
+    tiles.  Every GEMM of the forward walks 256-row tiles over the card's 256 CUs, so a launch costs ceil(tiles / 256) rounds
+    whatever the last round holds: at 4 s windows a batch of 128 is 100 row tiles, the out-projection and FFN2 (4 column
+    tiles each) then run 400 tiles = 1.56 rounds in the time of 2, and 164 windows (128 row tiles, 512 tiles = 2 rounds
+    exactly) go through in barely more time.  Measured hot-path rates (tools/batch_sweep.py, profiles/r03_batch_friendly.json):
+    4 s windows 16.2 audio-h/s at 128, 17.3 at 164, 16.5 at 512, 17.3 at 493; 10 s windows 16.9 at 64, 16.1 at 208, 16.9 at 197.
+    The model below counts rounds x (K x tile width) per GEMM of csrc/gemm256.hip.h's dispatch (conv1-6 and FFN1 on 256-wide
+    tiles, projection / QKV / out-projection / FFN2 on 192-wide ones) and ranks the candidates by rounds per window.
+    Since window packing every forward but a run's last holds exactly this many windows."""
+    window = int(round(chunk_duration_s * 16000))
+    lens, n = [], window
+    for k, s in ((10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)):
+        n = (n - k) // s + 1
+        lens.append(n)
+    if max_batch < 8 or lens[-1] < 1:
+        return max_batch
+    frames = lens[-1]
+
+    def rounds(tiles: int) -> int:
+        return -(-tiles // n_cus)
+
+    def cost_per_window(b: int) -> float:
+        t = 0.0
+        for i, k in enumerate((1536, 1536, 1536, 1536, 1024, 1024)):
+            t += rounds(-(-b * lens[i + 1] // 256) * 2) * k * 256
+        tm = -(-b * frames // 256)
+        t += rounds(tm * 4) * 512 * 192
+        t += 12 * (rounds(tm * 12) * 768 * 192 + rounds(tm * 12) * 768 * 256 + rounds(tm * 4) * 768 * 192 + rounds(tm * 4) * 3072 * 192)
+        return t / b
+
+    lo = max(1, int(max_batch * 0.8))
+    return min(range(max_batch, lo - 1, -1), key=lambda b: (round(cost_per_window(b) / cost_per_window(max_batch), 4), -b))

@@ -42,7 +42,7 @@ from ..audio import read_pcm, read_plain_wav_into
 from ..core.intervals import intervals_to_columns
 from ..core.metadata import vtc_error_row, vtc_meta_row_columns
 from ..engine import RF_SIZE
-from ..packing import OpenRecording, pack_forward, packed_decode_input
+from ..packing import OpenRecording, pack_forward, packed_decode_input, tile_friendly_batch
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -383,8 +383,10 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         model_config = Config()
     if batch_size <= 0:
         props = torch.cuda.get_device_properties(dev_index)
-        batch_size = recommend_vtc_batch_size(props.total_memory // (1024 ** 3), float(model_config.audio.chunk_duration_s))
-        logger.info(f"Auto batch_size={batch_size} for {props.name}, {model_config.audio.chunk_duration_s:g} s windows")
+        ladder = recommend_vtc_batch_size(props.total_memory // (1024 ** 3), float(model_config.audio.chunk_duration_s))
+        batch_size = tile_friendly_batch(ladder, float(model_config.audio.chunk_duration_s))
+        logger.info(f"Auto batch_size={batch_size} for {props.name}, {model_config.audio.chunk_duration_s:g} s windows "
+                    f"(memory ladder {ladder}, trimmed to whole rounds of GEMM tiles)")
 
     paths = get_dataset_paths(dataset)
     logger.info(f"Dataset: {dataset}")
