@@ -104,6 +104,31 @@ def packed_decode_input(done: list, out: torch.Tensor):
     return logits, rows, [o.n for o in done]
 
 
+def forward_cost_per_window(batch: int, chunk_duration_s: float, n_cus: int = 256):
+    """Relative GEMM time of one forward divided by its windows: rounds of 256-row tiles over n_cus CUs x (K x tile width), summed
+    over the GEMMs of csrc/vtc_api.hip's dispatch (conv1-6 and FFN1 on 256-wide tiles, projection / QKV / out-projection / FFN2
+    on 192-wide ones).  None when the window is shorter than the receptive field."""
+    window = int(round(chunk_duration_s * 16000))
+    lens, n = [], window
+    for k, s in ((10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)):
+        n = (n - k) // s + 1
+        lens.append(n)
+    if batch < 1 or lens[-1] < 1:
+        return None
+    frames = lens[-1]
+
+    def rounds(tiles: int) -> int:
+        return -(-tiles // n_cus)
+
+    t = 0.0
+    for i, k in enumerate((1536, 1536, 1536, 1536, 1024, 1024)):
+        t += rounds(-(-batch * lens[i + 1] // 256) * 2) * k * 256
+    tm = -(-batch * frames // 256)
+    t += rounds(tm * 4) * 512 * 192
+    t += 12 * (rounds(tm * 12) * 768 * 192 + rounds(tm * 12) * 768 * 256 + rounds(tm * 4) * 768 * 192 + rounds(tm * 4) * 3072 * 192)
+    return t / batch
+
+
 def tile_friendly_batch(max_batch: int, chunk_duration_s: float, n_cus: int = 256) -> int:
     """The batch size <= max_batch (and >= 80 % of it) at which the persistent GEMMs waste the least of their last round of
     tiles.  Every GEMM of the forward walks 256-row tiles over the card's 256 CUs, so a launch costs ceil(tiles / 256) rounds
@@ -111,29 +136,10 @@ def tile_friendly_batch(max_batch: int, chunk_duration_s: float, n_cus: int = 25
     tiles each) then run 400 tiles = 1.56 rounds in the time of 2, and 164 windows (128 row tiles, 512 tiles = 2 rounds
     exactly) go through in barely more time.  Measured hot-path rates (tools/batch_sweep.py, profiles/r03_batch_friendly.json):
     4 s windows 16.2 audio-h/s at 128, 17.3 at 164, 16.5 at 512, 17.3 at 493; 10 s windows 16.9 at 64, 16.1 at 208, 16.9 at 197.
-    The model below counts rounds x (K x tile width) per GEMM of csrc/gemm256.hip.h's dispatch (conv1-6 and FFN1 on 256-wide
-    tiles, projection / QKV / out-projection / FFN2 on 192-wide ones) and ranks the candidates by rounds per window.
+    The candidates are ranked by forward_cost_per_window (rounds x tile work per window).
     Since window packing every forward but a run's last holds exactly this many windows."""
-    window = int(round(chunk_duration_s * 16000))
-    lens, n = [], window
-    for k, s in ((10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)):
-        n = (n - k) // s + 1
-        lens.append(n)
-    if max_batch < 8 or lens[-1] < 1:
+    if max_batch < 8 or forward_cost_per_window(max_batch, chunk_duration_s, n_cus) is None:
         return max_batch
-    frames = lens[-1]
-
-    def rounds(tiles: int) -> int:
-        return -(-tiles // n_cus)
-
-    def cost_per_window(b: int) -> float:
-        t = 0.0
-        for i, k in enumerate((1536, 1536, 1536, 1536, 1024, 1024)):
-            t += rounds(-(-b * lens[i + 1] // 256) * 2) * k * 256
-        tm = -(-b * frames // 256)
-        t += rounds(tm * 4) * 512 * 192
-        t += 12 * (rounds(tm * 12) * 768 * 192 + rounds(tm * 12) * 768 * 256 + rounds(tm * 4) * 768 * 192 + rounds(tm * 4) * 3072 * 192)
-        return t / b
-
+    ref = forward_cost_per_window(max_batch, chunk_duration_s, n_cus)
     lo = max(1, int(max_batch * 0.8))
-    return min(range(max_batch, lo - 1, -1), key=lambda b: (round(cost_per_window(b) / cost_per_window(max_batch), 4), -b))
+    return min(range(max_batch, lo - 1, -1), key=lambda b: (round(forward_cost_per_window(b, chunk_duration_s, n_cus) / ref, 4), -b))

@@ -42,7 +42,7 @@ from ..audio import read_pcm, read_plain_wav_into
 from ..core.intervals import intervals_to_columns
 from ..core.metadata import vtc_error_row, vtc_meta_row_columns
 from ..engine import RF_SIZE
-from ..packing import OpenRecording, pack_forward, packed_decode_input, tile_friendly_batch
+from ..packing import OpenRecording, forward_cost_per_window, pack_forward, packed_decode_input, tile_friendly_batch
 from ..segma_compat.config import load_config
 from ..segma_compat.config.base import Config
 from ..segma_compat.inference import logit_bounds
@@ -387,6 +387,14 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
         batch_size = tile_friendly_batch(ladder, float(model_config.audio.chunk_duration_s))
         logger.info(f"Auto batch_size={batch_size} for {props.name}, {model_config.audio.chunk_duration_s:g} s windows "
                     f"(memory ladder {ladder}, trimmed to whole rounds of GEMM tiles)")
+    else:
+        # an explicit batch is respected; say so when a nearby one would fill the GEMMs' last round of tiles much better
+        chunk = float(model_config.audio.chunk_duration_s)
+        near = tile_friendly_batch(int(batch_size * 1.3), chunk)
+        mine, best = forward_cost_per_window(batch_size, chunk), forward_cost_per_window(near, chunk)
+        if mine and best and mine / best > 1.03:
+            logger.info(f"batch_size {batch_size}: its GEMM launches leave part of their last round of tiles empty; "
+                        f"{near} windows per forward would be ~{100 * (mine / best - 1):.0f} % faster per window")
 
     paths = get_dataset_paths(dataset)
     logger.info(f"Dataset: {dataset}")
