@@ -245,3 +245,108 @@ def test_threaded_decode_equals_sequential():
         n, out = C.c_int64(), np.empty((len(x), x.shape[1]), dtype=np.int16)
         rc = lib.vtc_flac_decode_threads(bytes(bad), len(bad), C.c_void_p(out.ctypes.data), 0, len(x), C.byref(n), 4)
         assert rc == L.ERR_ARG, name
+
+
+def _ogg_pages(packets, serial=0x1234, max_page=4000, header_packets=0):
+    """Test muxer (RFC 3533): packets -> pages of at most max_page body bytes, packets continued across pages; the first
+    `header_packets` + 1 packets get pages of their own, as the FLAC mapping asks."""
+    from vtc_amd.audio import ogg_crc32
+    pages, seq = [], 0
+    cur_table, cur_body, cont = [], b"", False
+
+    def flush(first_flag_cont, last=False):
+        nonlocal cur_table, cur_body, seq
+        if not cur_table:
+            return
+        flags = (1 if first_flag_cont else 0) | (2 if seq == 0 else 0) | (4 if last else 0)
+        hdr = b"OggS" + struct.pack("<BBqIIIB", 0, flags, 0, serial, seq, 0, len(cur_table)) + bytes(cur_table)
+        page = bytearray(hdr + cur_body)
+        page[22:26] = struct.pack("<I", ogg_crc32(page))
+        pages.append(bytes(page))
+        seq += 1
+        cur_table, cur_body = [], b""
+
+    page_cont = False
+    for k, pkt in enumerate(packets):
+        segs = [pkt[i:i + 255] for i in range(0, len(pkt), 255)]
+        if not segs or len(segs[-1]) == 255:
+            segs.append(b"")
+        for j, sg in enumerate(segs):
+            if len(cur_table) == 255 or (cur_table and len(cur_body) + len(sg) > max_page):
+                flush(page_cont)
+                page_cont = j > 0           # the new page starts in the middle of this packet
+            cur_table.append(len(sg))
+            cur_body += sg
+        if k <= header_packets:
+            flush(page_cont)
+            page_cont = False
+    flush(page_cont, last=True)
+    return b"".join(pages)
+
+
+def _flac_frames(stream):
+    """Split a native FLAC stream written by the test encoder into (metadata blocks, frames): a frame ends where the CRC-16
+    of everything since its start is followed by the next sync code (or the end of the stream)."""
+    assert stream[:4] == b"fLaC"
+    pos, blocks = 4, []
+    while True:
+        last, size = stream[pos] & 0x80, int.from_bytes(stream[pos + 1:pos + 4], "big")
+        blocks.append(stream[pos:pos + 4 + size])
+        pos += 4 + size
+        if last:
+            break
+    frames, start = [], pos
+    while start < len(stream):
+        end = start + 6
+        while True:
+            nxt = stream.find(b"\xff\xf8", end) if stream[start + 1] == 0xF8 else stream.find(b"\xff\xf9", end)
+            cand = len(stream) if nxt < 0 else nxt
+            if F.crc16(stream[start:cand - 2]) == int.from_bytes(stream[cand - 2:cand], "big"):
+                frames.append(stream[start:cand])
+                start = cand
+                break
+            assert nxt >= 0, "frame boundary not found"
+            end = nxt + 1
+    return blocks, frames
+
+
+def test_ogg_container_crc_flac_mapping_and_codec_names(tmp_path):
+    """`.ogg` is on the reference's manifest list (scripts/make_manifest.py:26-39).  The container is parsed (RFC 3533); FLAC in
+    Ogg (RFC 9639 section 10.1) is decoded through the library's FLAC decoder; Vorbis / Opus streams raise with the codec's name.
+    The page CRC (not zlib's CRC-32) is pinned by a real Ogg Vorbis file, a 0.5 s interface sound shipped with MathJax
+    (Apache-2.0), copied to tests/golden/ogg_vorbis_beep.ogg: all of its pages must verify."""
+    from vtc_amd.audio import decode_ogg, ogg_crc32, ogg_packets
+    real = (GOLDEN / "ogg_vorbis_beep.ogg").read_bytes()
+    pkts = ogg_packets(real, check_pages=-1)                       # raises if any page fails its CRC
+    assert len(pkts) == 29 and bytes(pkts[0][:7]) == b"\x01vorbis" and bytes(pkts[1][:7]) == b"\x03vorbis"
+    damaged = bytearray(real)
+    damaged[100] ^= 0x10
+    with pytest.raises(ValueError, match="CRC"):
+        ogg_packets(bytes(damaged), check_pages=-1)
+    assert ogg_crc32(b"") == 0 and ogg_crc32(b"\x01") == 0x04C11DB7   # the polynomial itself, unreflected
+    (tmp_path / "beep.ogg").write_bytes(real)
+    with pytest.raises(ValueError, match="carries Vorbis"):
+        read_pcm(tmp_path / "beep.ogg")
+    opus_head = b"OpusHead" + bytes([1, 1]) + struct.pack("<HIhB", 312, 48000, 0, 0)
+    (tmp_path / "o.opus").write_bytes(_ogg_pages([opus_head, b"OpusTags" + bytes(8), bytes(40)]))
+    with pytest.raises(ValueError, match="carries Opus"):
+        read_pcm(tmp_path / "o.opus")
+
+    # FLAC in Ogg: mono and stereo, small pages so that frames continue across pages, with and without the header count
+    for nch, sr, page, declared in ((1, 16000, 4000, True), (2, 44100, 700, True), (1, 8000, 60000, False)):
+        x = tone(30000, nch, 16, seed=nch)
+        native = F.encode(x, sr, blocksize=1152 if nch == 2 else 4096)
+        blocks, frames = _flac_frames(native)
+        assert len(frames) == -(-30000 // (1152 if nch == 2 else 4096))
+        ident = b"\x7fFLAC" + bytes([1, 0]) + (len(blocks) - 1 if declared else 0).to_bytes(2, "big") + b"fLaC" + blocks[0]
+        ogg = _ogg_pages([ident] + blocks[1:] + frames, max_page=page, header_packets=len(blocks) - 1)
+        got, got_sr = decode_ogg(ogg)
+        assert got_sr == sr and np.array_equal(got, as_decoded(x, 16))
+        p = tmp_path / f"f{nch}_{page}.oga"
+        p.write_bytes(ogg)
+        again, _ = read_pcm(p)
+        assert np.array_equal(again, got)
+        bad = bytearray(ogg)
+        bad[len(ogg) // 2] ^= 0x01                                   # inside an audio page: the FLAC frame CRC catches it
+        with pytest.raises(Exception):
+            decode_ogg(bytes(bad))

@@ -5,7 +5,8 @@ non-16 kHz or multi-channel input is unpinned.  Here: WAV
 mu-law, 4-bit IMA ADPCM, RF64 / BW64 headers; own RIFF parser or scipy), FLAC (the library's RFC 9639 decoder, vtc_flac_decode), AIFF / AIFF-C PCM; channels are averaged;
 other rates are resampled with torchaudio's windowed-sinc polyphase filter (sinc_interp_hann, width 6, rolloff 0.99).
 The lossy formats of scripts/make_manifest.py:26-39 (mp3, ogg, opus, m4a, aac, wma) need codecs that are not available
-offline; they raise, which the pipeline turns into an error row.
+offline; they raise, which the pipeline turns into an error row.  An .ogg / .oga file is opened as far as its container: FLAC
+in Ogg is decoded, Vorbis / Opus / Speex raise with the codec's name.
 
 Two routes give the same samples: `read_pcm` + `VtcEngine.prepare_audio` (raw PCM is copied to the GPU and
 mixed / resampled there: the pipeline's route) and `read_audio` (all on the host: tests, small tools).
@@ -294,6 +295,99 @@ def _file_bytes(path: Path):
 
 UNSUPPORTED_LOSSY = (".mp3", ".ogg", ".opus", ".m4a", ".aac", ".wma")
 
+_OGG_CRC = None
+
+
+def ogg_crc32(page) -> int:
+    """CRC of an Ogg page (RFC 3533 section 6: polynomial 0x04c11db7, initial value 0, no bit reflection, no final XOR;
+    computed with the page's own checksum field zeroed).  Not zlib's CRC-32."""
+    global _OGG_CRC
+    if _OGG_CRC is None:
+        t = []
+        for i in range(256):
+            r = i << 24
+            for _ in range(8):
+                r = ((r << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if r & 0x80000000 else (r << 1) & 0xFFFFFFFF
+            t.append(r)
+        _OGG_CRC = t
+    t, crc = _OGG_CRC, 0
+    for b in bytes(page):
+        crc = ((crc << 8) & 0xFFFFFFFF) ^ t[((crc >> 24) ^ b) & 0xFF]
+    return crc
+
+
+OGG_CODECS = ((b"\x7fFLAC", "FLAC"), (b"\x01vorbis", "Vorbis"), (b"OpusHead", "Opus"), (b"Speex   ", "Speex"), (b"\x80theora", "Theora"))
+
+
+def ogg_packets(data, check_pages: int = 8):
+    """Packets of the first logical bitstream of an Ogg file (RFC 3533): pages are 'OggS' + a 27-byte header + a segment table;
+    a packet is the run of segments up to the first one shorter than 255 bytes, possibly continued on the next page.  The page
+    CRC is verified on the first `check_pages` pages (the header packets; -1 = all): audio packets of the one codec decoded here
+    (FLAC) carry their own frame CRCs, which the FLAC decoder checks.  Returns a list of memoryviews / bytes."""
+    import struct
+
+    buf = memoryview(np.ascontiguousarray(data).view(np.uint8)) if isinstance(data, np.ndarray) else memoryview(data)
+    pos, n, serial, page_no = 0, len(buf), None, 0
+    packets, parts = [], []
+    while pos + 27 <= n:
+        if bytes(buf[pos:pos + 4]) != b"OggS":
+            raise ValueError(f"Ogg: no page at byte {pos}")
+        version, flags, _gran, ser, _seq, crc, nseg = struct.unpack("<BBqIIIB", buf[pos + 4:pos + 27])
+        if version != 0 or pos + 27 + nseg > n:
+            raise ValueError("Ogg: bad page header")
+        table = bytes(buf[pos + 27:pos + 27 + nseg])
+        body = pos + 27 + nseg
+        size = sum(table)
+        if body + size > n:
+            raise ValueError("Ogg: truncated page")
+        if check_pages < 0 or page_no < check_pages:
+            page = bytearray(buf[pos:body + size])
+            page[22:26] = b"\0\0\0\0"
+            if ogg_crc32(page) != crc:
+                raise ValueError(f"Ogg: page {page_no} fails its CRC")
+        if serial is None:
+            serial = ser
+        if ser == serial:                       # other logical streams of a multiplexed file are skipped
+            if not (flags & 1) and parts:       # a fresh packet starts although the previous one never ended: drop the torso
+                parts = []
+            at = body
+            for seg in table:
+                parts.append(buf[at:at + seg])
+                at += seg
+                if seg < 255:
+                    packets.append(parts[0] if len(parts) == 1 else b"".join(parts))
+                    parts = []
+        pos = body + size
+        page_no += 1
+    if not packets:
+        raise ValueError("Ogg: no packets")
+    return packets
+
+
+def decode_ogg(data):
+    """Ogg file held in memory -> (samples, sample_rate).  FLAC in Ogg (the mapping of RFC 9639 section 10.1: a first packet
+    0x7F 'FLAC' major minor n_header_packets 'fLaC' STREAMINFO, then one metadata block per header packet, then one FLAC frame
+    per packet) is re-assembled into a native FLAC stream and decoded by the library (frame CRCs checked).  Vorbis, Opus and
+    Speex streams raise with the codec's name: there is no decoder for them in this build."""
+    packets = ogg_packets(data)
+    head = bytes(packets[0][:16])
+    codec = next((name for magic, name in OGG_CODECS if head.startswith(magic)), None)
+    if codec != "FLAC":
+        raise ValueError(f"Ogg stream carries {codec or 'an unknown codec'}; this build decodes FLAC in Ogg only "
+                         "(no Vorbis / Opus decoder is available offline)")
+    first = bytes(packets[0])
+    if len(first) < 13 + 4 + 34 or first[9:13] != b"fLaC" or first[5] != 1:
+        raise ValueError("Ogg FLAC: malformed identification packet (mapping version 1.x expected)")
+    n_headers = (first[7] << 8) | first[8]      # 0 = unknown: metadata packets are then told from frames by their first bytes
+    meta, k = [first[13:]], 1
+    while k < len(packets) and (k <= n_headers if n_headers else bytes(packets[k][:1]) != b"\xff"):
+        meta.append(bytes(packets[k]))
+        k += 1
+    # exactly one block may carry the last-metadata-block flag: the last one
+    blocks = [bytes([b[0] & 0x7F]) + b[1:] for b in meta[:-1]] + [bytes([meta[-1][0] | 0x80]) + meta[-1][1:]]
+    stream = b"fLaC" + b"".join(blocks) + b"".join(bytes(p) if not isinstance(p, bytes) else p for p in packets[k:])
+    return decode_flac(stream)
+
 
 def read_pcm(path):
     """Decode only as far as the container: (samples, sample_rate) with samples int16 or float32, shape (n,) or
@@ -304,6 +398,11 @@ def read_pcm(path):
         return decode_flac(_file_bytes(path))
     if ext in (".aiff", ".aif", ".aifc"):
         return decode_aiff(_file_bytes(path))
+    if ext in (".ogg", ".oga", ".opus"):
+        try:
+            return decode_ogg(_file_bytes(path))
+        except ValueError as e:
+            raise ValueError(f"{path.name}: {e}") from None
     if ext not in (".wav", ".wave"):
         why = "needs a codec that is not available in this build" if ext in UNSUPPORTED_LOSSY else "unknown audio format"
         raise ValueError(f"{path.name}: '{ext}' {why} (supported: wav, flac, aiff)")
