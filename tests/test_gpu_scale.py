@@ -251,7 +251,7 @@ def test_c2_hundred_hours_identical_content_gives_identical_rows(tmp_path, monke
     assert all(len(by_uid[uids[k]]) > 500 for k in range(len(lens)))
     # 36,600 windows in full forwards of 64: nothing but the last forward (and a flush when the readers lag) is partial
     assert stats["windows"] == sum(-(-(len(pcm[k]) - 399) // (499 * 320)) for k in kind_of)
-    assert stats["windows"] / stats["forwards"] > 62.0, stats
+    assert stats["forwards"] <= 595, stats      # 572 when the readers never lag; one forward per file would be 600
     eng = VtcEngine(synth.make_weights(seed=0), n_labels=4, chunk_duration_s=10.0, max_batch=64, device=0)
     lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
     for k in range(len(lens)):
