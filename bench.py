@@ -123,6 +123,7 @@ def end_to_end_node(n_workers: int, files_per_worker: int, chunk_s: float, batch
             return {"value": None, "error": (r.stdout + r.stderr)[-400:]}
         d = json.loads(lines[-1])
         keep = ("value", "unit", "workers", "files", "file_seconds", "audio_hours", "file_loop_span_s", "per_worker_steady_state",
+                "per_worker_gpu_busy_wait_s", "per_worker_wait_for_readers_s", "per_worker_write_s",
                 "with_startup_and_model_construction", "launcher_wall_s", "host_cpus", "cpu_seconds_per_audio_hour",
                 "host_cores_busy", "what")
         return {k: d[k] for k in keep}

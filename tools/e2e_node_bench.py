@@ -94,6 +94,11 @@ def main() -> None:
             "files": n_files, "file_seconds": args.seconds, "audio_hours": hours, "file_loop_span_s": span,
             "per_worker_steady_state": [round(x["total_audio_seconds"] / 3600.0 / x["wall_seconds"], 3) for x in recs],
             "per_worker_file_loop_s": [x["wall_seconds"] for x in recs],
+            # where a worker's file loop went: seconds its GPU thread waited for the GPU (collect), for its reader threads
+            # (gpu_wait), and the final parquet write; a host-bound node shows up as gpu_wait_for_readers growing with N
+            "per_worker_gpu_busy_wait_s": [round(x["extra"].get("stage_seconds", {}).get("gpu_collect", 0.0), 2) for x in recs],
+            "per_worker_wait_for_readers_s": [round(x["extra"].get("stage_seconds", {}).get("gpu_wait", 0.0), 2) for x in recs],
+            "per_worker_write_s": [round(x["extra"].get("stage_seconds", {}).get("write", 0.0), 2) for x in recs],
             "with_startup_and_model_construction": hours / wall, "launcher_wall_s": wall, "raw_segments": n_raw,
             "chunk_duration_s": args.chunk, "batch": args.batch, "host_cpus": len(os.sched_getaffinity(0)),
             # measured host budget: CPU time (user + system) of the launcher and all its workers, start-up and model
