@@ -597,6 +597,28 @@ def test_batch_size_recommendation():
     assert -(-491 * 199 // 256) == 382
 
 
+def test_tile_round_model_agrees_with_the_measured_batch_sweep():
+    """packing.py::forward_cost_per_window (rounds of GEMM tiles per window) against the hot-path rates measured on the MI355X at
+    the same batch sizes (profiles/r03_batch_friendly.json, tools/batch_sweep.py): wherever the model says one batch is at least
+    4 % cheaper per window than another, the measurement must agree on the direction, and the batches the model calls within
+    1 % of each other were measured within 2.5 %."""
+    from vtc_amd.packing import forward_cost_per_window as cost
+    pts = json.loads((Path(__file__).parent.parent / "profiles" / "r03_batch_friendly.json").read_text())["points"]
+    for chunk in (4.0, 10.0):
+        sel = [(p["batch"], p["audio_hours_per_s"]) for p in pts if p["chunk_duration_s"] == chunk]
+        assert len(sel) >= 8
+        checked = 0
+        for b1, r1 in sel:
+            for b2, r2 in sel:
+                c1, c2 = cost(b1, chunk), cost(b2, chunk)
+                if c1 < 0.96 * c2:
+                    assert r1 > r2, (chunk, b1, b2, r1, r2)
+                    checked += 1
+                elif abs(c1 / c2 - 1) < 0.01:
+                    assert abs(r1 / r2 - 1) < 0.025, (chunk, b1, b2, r1, r2)
+        assert checked >= 3, (chunk, checked)
+
+
 def test_launcher_cpu_slices_and_thread_budget():
     """Eight workers share a node: each gets an equal contiguous CPU slice and pools sized from it (launcher docstring)."""
     from vtc_amd.launcher import thread_budget, worker_cpu_slices
