@@ -177,7 +177,8 @@ int vtc_decode_collect(vtc_model* m, int32_t* out_file /*[host]*/, int64_t* out_
 
 /* Audio front-end of apply_model_on_audio (src/pipeline/vtc.py:236-243 decodes the file to mono 16 kHz float inside
  * segma before the model runs): interleaved PCM already in device memory -> mono float32 at 16 kHz, on `stream`.
- *   format 0 = int16 (scaled by 1/32768), 1 = float32; channels are averaged; sr_in != 16000 is resampled with the
+ *   format 0 = int16 (scaled by 1/32768), 1 = float32, 2 = packed little-endian int24 (3 bytes per sample, scaled by 1/2^23:
+ *   24-bit PCM WAVs cross PCIe as stored); channels are averaged; sr_in != 16000 is resampled with the
  *   windowed-sinc polyphase filter of torchaudio.functional.resample (sinc_interp_hann, width 6, rolloff 0.99), the
  *   library the reference pulls in through segma (requirements.txt:393-394).  The rule itself is unpinned.
  * *n_out = vtc_resampled_length(n_in, sr_in) = ceil(n_in * 16000 / sr_in); VTC_ERR_CAPACITY if out_cap is smaller.

@@ -625,7 +625,8 @@ def test_cli_durable_progress_and_resume_after_crash(tmp_path, monkeypatch):
 
 # ----------------------------------------------------------------------------- audio front-end
 @pytest.mark.parametrize("sr,ch,dtype", [(16000, 1, "int16"), (16000, 2, "int16"), (44100, 2, "int16"), (48000, 1, "float32"),
-                                         (8000, 1, "int16"), (22050, 3, "float32"), (32000, 1, "int16")])
+                                         (8000, 1, "int16"), (22050, 3, "float32"), (32000, 1, "int16"),
+                                         (16000, 1, "int24"), (48000, 2, "int24")])
 def test_gpu_front_end_against_oracle(weights, sr, ch, dtype):
     """vtc_prepare_audio (channel mix + windowed-sinc resampling on the GPU) against the oracle's restatement of
     torchaudio.functional.resample and against the host route (audio.sinc_resample).  int16 -> float and the mono mix
@@ -634,19 +635,74 @@ def test_gpu_front_end_against_oracle(weights, sr, ch, dtype):
     rng = np.random.default_rng(sr + ch)
     n = int(1.37 * sr) + 13
     x = rng.standard_normal((n, ch)) * 0.2
-    pcm = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16) if dtype == "int16" else x.astype(np.float32)
+    packed = None
+    if dtype == "int24":       # packed 24-bit PCM as a WAV stores it (format 2): exact in float32, so the oracle takes the floats
+        v = np.clip(np.round(x * 8388608), -8388608, 8388607).astype(np.int32)
+        packed = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8)
+        pcm = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+        assert np.array_equal(audio.pcm24_to_float32(packed).reshape(n, ch), pcm)
+    else:
+        pcm = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16) if dtype == "int16" else x.astype(np.float32)
     if ch == 1:
         pcm = pcm[:, 0].copy()
     mono = O.pcm_to_mono_float(pcm)
     ref = O.resample_sinc_hann(mono, sr)
     eng = _engine(weights, 1.0, 2)
-    got = eng.prepare_audio(torch.from_numpy(pcm).cuda(), sr).cpu().numpy()
+    got = eng.prepare_audio(torch.from_numpy(packed if packed is not None else pcm).cuda(), sr).cpu().numpy()
     assert got.shape == ref.shape == (-(-16000 * n // sr),)
     if sr == 16000:
         assert np.array_equal(got, mono)                       # conversion and mix: bit exact
     else:
         assert np.abs(got - ref).max() <= 2e-6
         assert np.abs(got - audio.sinc_resample(mono, sr)).max() <= 2e-6
+    eng.close()
+
+
+def test_cli_24_bit_wav_files_cross_pcie_packed(weights, tmp_path, monkeypatch):
+    """24-bit PCM WAVs (mono 16 kHz and stereo 48 kHz) through the CLI: read_pcm hands the packed bytes to the GPU front-end
+    (vtc_prepare_audio format 2), no host conversion.  Rows must equal those of the same samples converted on the host
+    (audio.read_audio for the mono file: the conversion is exact, so this is bit for bit)."""
+    import struct
+    from vtc_amd import audio
+    from vtc_amd.pipeline import vtc as cli
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "manifests").mkdir()
+    (tmp_path / "audio").mkdir()
+
+    def wav24(path, v, sr):
+        n, ch = v.shape
+        b = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8).tobytes()
+        path.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(b)) + b"WAVEfmt " +
+                         struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * ch * 3, ch * 3, 24) + b"data" + struct.pack("<I", len(b)) + b)
+
+    x = synth.synth_audio(23.4, seed=77)
+    mono = np.clip(np.round(x * 8388608.0), -8388608, 8388607).astype(np.int32)[:, None]
+    wav24(tmp_path / "audio" / "m24.wav", mono, 16000)
+    up = np.interp(np.arange(int(9.1 * 48000)) / 48000.0, np.arange(len(x)) / 16000.0, x)
+    st = np.clip(np.round(np.stack([up, 0.5 * up], axis=1) * 8388608.0), -8388608, 8388607).astype(np.int32)
+    wav24(tmp_path / "audio" / "s24.wav", st, 48000)
+    (tmp_path / "manifests" / "w24.csv").write_text(f"path\n{tmp_path / 'audio' / 'm24.wav'}\n{tmp_path / 'audio' / 's24.wav'}\n")
+    (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
+    got, _ = audio.read_pcm(tmp_path / "audio" / "s24.wav")
+    assert got.dtype == np.uint8 and got.shape == (len(st), 2, 3)
+    cli.main("w24", config=str(tmp_path / "cfg.yml"), checkpoint="synthetic:0", batch_size=8)
+    out = tmp_path / "output" / "w24"
+    seg = pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist()
+    meta = pq.read_table(out / "vtc_meta" / "shard_0.parquet").to_pylist()
+    assert [r["uid"] for r in meta] == ["m24", "s24"] and all(r["error"] == "" for r in meta)
+    eng = _engine(weights, 4.0, 8)
+    lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
+    for uid in ("m24", "s24"):
+        if uid == "m24":
+            wav = torch.from_numpy(audio.read_audio(tmp_path / "audio" / "m24.wav")).cuda()      # host route: exact conversion
+        else:
+            wav = eng.prepare_audio(torch.from_numpy(np.ascontiguousarray(got)).cuda(), 48000)
+            host = audio.read_audio(tmp_path / "audio" / "s24.wav")                              # host mix + resample: fp32 sums
+            assert np.abs(wav.cpu().numpy() - host).max() <= 2e-6
+        s_, e_, l_, _, _ = eng.decode(eng.infer_waveform(wav, batch_size=8).contiguous(), lo, hi)
+        want = O.intervals_to_segments([(int(a), int(b), O.DEFAULT_LABELS[int(c)]) for a, b, c in zip(s_, e_, l_)], uid)
+        mine = [(r["onset"], r["offset"], r["duration"], r["label"]) for r in seg if r["uid"] == uid]
+        assert mine == [(r["onset"], r["offset"], r["duration"], r["label"]) for r in want] and len(mine) > 3, uid
     eng.close()
 
 

@@ -727,6 +727,22 @@ def test_fast_wav_reader_matches_scipy(tmp_path):
             assert got.dtype == x.dtype and np.array_equal(got, x)
         else:
             assert audio._fast_wav(tmp_path / name) is None and got.dtype == np.float32
+    # 24-bit PCM (what field recorders write): the reader hands back the packed bytes, uint8 (n, channels, 3), for the GPU
+    # front-end to unpack; the host route (pcm24_to_float32) gives exactly what scipy's left-justified int32 / 2^31 gives
+    for name, ch, sr in (("m24.wav", 1, 48000), ("s24.wav", 2, 44100)):
+        v = rng.integers(-(1 << 23), 1 << 23, (601, ch)).astype(np.int32)
+        v[0], v[1] = (1 << 23) - 1, -(1 << 23)
+        b = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8)
+        data = b.tobytes()
+        hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * ch * 3, ch * 3, 24) + \
+            b"data" + struct.pack("<I", len(data))
+        (tmp_path / name).write_bytes(hdr + data)
+        got, gsr = audio.read_pcm(tmp_path / name)
+        assert gsr == sr and got.dtype == np.uint8 and got.shape == (601, ch, 3) and np.array_equal(got, b)
+        ssr, sx = wavfile.read(tmp_path / name)
+        assert ssr == sr and np.array_equal(audio.pcm24_to_float32(got).reshape(601, ch), audio.to_float32(sx).reshape(601, ch))
+        want = audio.to_float32(sx).reshape(601, ch).mean(axis=1, dtype=np.float32)
+        assert np.array_equal(audio.read_audio(tmp_path / name), audio.sinc_resample(want, sr))
     # a LIST chunk of odd length before the data chunk, and a data size field larger than the file (truncated recording)
     raw = (tmp_path / "m16.wav").read_bytes()
     i = raw.index(b"data")
@@ -931,7 +947,7 @@ def test_damaged_audio_files_raise_and_never_hang(tmp_path):
             p.write_bytes(bytes(d))
             try:
                 got, sr = read_pcm(p)
-                assert got.dtype in (np.int16, np.float32) and got.nbytes < (64 << 20)
+                assert got.dtype in (np.int16, np.float32, np.uint8) and got.nbytes < (64 << 20)
                 outcomes["ok"] += 1
             except Exception as e:       # anything that is an Exception becomes an error row; a crash or a hang would not get here
                 outcomes[type(e).__name__] = outcomes.get(type(e).__name__, 0) + 1

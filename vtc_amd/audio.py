@@ -37,6 +37,16 @@ def to_float32(data: np.ndarray) -> np.ndarray:
     return out
 
 
+def pcm24_to_float32(packed: np.ndarray) -> np.ndarray:
+    """Packed little-endian 24-bit PCM, uint8 (n, channels, 3) as read_pcm returns it -> float32 (n,) or (n, channels) =
+    integer / 2^23 (exact in float32; what scipy's left-justified int32 / 2^31 gives).  Host route (read_audio, tools)."""
+    b = np.asarray(packed).astype(np.int32)
+    v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    v = np.where(v & 0x800000, v - (1 << 24), v)
+    out = (v.astype(np.float32) / np.float32(8388608.0))
+    return out[:, 0] if out.shape[1] == 1 else out
+
+
 def g711_table(law: str) -> np.ndarray:
     """ITU-T G.711 expansion, 256 codes -> 16-bit linear PCM (the tables of the Recommendation, as every decoder has
     them).  mu-law: complement the byte; value = ((mantissa << 3) + 132 << exponent) - 132, sign bit set = negative
@@ -89,10 +99,11 @@ def _wav_layout(f):
                 return None
             tag, ch, sr, bits = fmt
             kind = (np.int16 if (tag == 1 and bits == 16) else np.float32 if (tag == 3 and bits == 32) else
-                    "alaw" if (tag == 6 and bits == 8) else "ulaw" if (tag == 7 and bits == 8) else None)
+                    "alaw" if (tag == 6 and bits == 8) else "ulaw" if (tag == 7 and bits == 8) else
+                    "pcm24" if (tag == 1 and bits == 24) else None)
             if kind is None or ch < 1:
                 return None
-            width = 1 if isinstance(kind, str) else np.dtype(kind).itemsize
+            width = 3 if kind == "pcm24" else 1 if isinstance(kind, str) else np.dtype(kind).itemsize
             offset = f.tell()
             avail = os.fstat(f.fileno()).st_size - offset
             if size == 0xFFFFFFFF and data64 is not None:
@@ -113,11 +124,14 @@ def _fast_wav(path: Path):
             return None
         kind, ch, sr, offset, n = lay
         dtype = np.uint8 if isinstance(kind, str) else kind
-        if n * ch * np.dtype(dtype).itemsize >= (8 << 20):
-            data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(n * ch,))
+        count = n * ch * (3 if kind == "pcm24" else 1)
+        if count * np.dtype(dtype).itemsize >= (8 << 20):
+            data = np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=(count,))
         else:
             f.seek(offset)
-            data = np.fromfile(f, dtype=dtype, count=n * ch)
+            data = np.fromfile(f, dtype=dtype, count=count)
+        if kind == "pcm24":
+            return data.reshape(n, ch, 3), sr      # packed bytes as stored: the GPU front-end unpacks them (format 2)
         if isinstance(kind, str):
             data = g711_table(kind)[data]          # 8-bit companded -> int16: from here on the PCM16 route
         return (data.reshape(n, ch) if ch > 1 else data), sr
@@ -391,7 +405,8 @@ def decode_ogg(data):
 
 def read_pcm(path):
     """Decode only as far as the container: (samples, sample_rate) with samples int16 or float32, shape (n,) or
-    (n, channels), memory-mapped when large.  Mixing and resampling are left to the GPU."""
+    (n, channels), memory-mapped when large; 24-bit PCM WAVs come back as their packed bytes, uint8 (n, channels, 3)
+    (VtcEngine.prepare_audio unpacks them on the GPU, pcm24_to_float32 on the host).  Mixing and resampling are left to the GPU."""
     path = Path(path)
     ext = path.suffix.lower()
     if ext == ".flac":
@@ -462,7 +477,7 @@ def read_audio(path) -> np.ndarray:
     exception into an error row (reference src/pipeline/vtc.py:245-249)."""
     path = Path(path)
     data, sr = read_pcm(path)
-    x = to_float32(np.asarray(data))
+    x = pcm24_to_float32(data) if (data.dtype == np.uint8 and data.ndim == 3) else to_float32(np.asarray(data))
     if x.ndim == 2:
         x = x.mean(axis=1, dtype=np.float32)
     if sr != SAMPLE_RATE:

@@ -16,7 +16,9 @@ struct ResampleTable {
   const int* first;      // [new_] index of the first stored tap inside the full (2*width + orig)-tap kernel
 };
 
-template <bool I16>
+// FMT: 0 = int16, 1 = float32, 2 = packed little-endian int24 (3 bytes per sample, as a 24-bit PCM WAV stores them; value / 2^23,
+// which float32 holds exactly)
+template <int FMT>
 __global__ __launch_bounds__(256) void prepare_audio_kernel(const void* __restrict__ pcm, long long n_in, int ch,
                                                             ResampleTable rt, float* __restrict__ out, long long n_out) {
   const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -24,8 +26,13 @@ __global__ __launch_bounds__(256) void prepare_audio_kernel(const void* __restri
   auto mono = [&](long long i) -> float {   // mean over channels, summed in channel order
     float s = 0.f;
     for (int c = 0; c < ch; ++c) {
-      if constexpr (I16) s += (float)((const short*)pcm)[i * ch + c] * (1.0f / 32768.0f);
-      else               s += ((const float*)pcm)[i * ch + c];
+      if constexpr (FMT == 0) s += (float)((const short*)pcm)[i * ch + c] * (1.0f / 32768.0f);
+      else if constexpr (FMT == 1) s += ((const float*)pcm)[i * ch + c];
+      else {
+        const unsigned char* b = (const unsigned char*)pcm + (i * ch + c) * 3;
+        const int v = (int)((unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)(signed char)b[2] << 16));
+        s += (float)v * (1.0f / 8388608.0f);
+      }
     }
     return ch == 1 ? s : s / (float)ch;
   };

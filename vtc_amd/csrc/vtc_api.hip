@@ -1303,7 +1303,7 @@ int vtc_prepare_audio(vtc_model* m, const void* pcm, int32_t format, int64_t n_i
                       float* out, int64_t out_cap, int64_t* n_out, void* stream) {
   if (!m) return VTC_ERR_ARG;
   if (!pcm || !out || !n_out) return fail(m, VTC_ERR_ARG, "null argument");
-  if (format != 0 && format != 1) return fail(m, VTC_ERR_ARG, "format must be 0 (int16) or 1 (float32)");
+  if (format < 0 || format > 2) return fail(m, VTC_ERR_ARG, "format must be 0 (int16), 1 (float32) or 2 (packed int24)");
   if (n_channels < 1 || n_channels > 64) return fail(m, VTC_ERR_ARG, "n_channels %d out of range 1..64", n_channels);
   if (sr_in < 1000 || sr_in > 768000) return fail(m, VTC_ERR_ARG, "sample rate %d out of range 1000..768000", sr_in);
   if (n_in < 0) return fail(m, VTC_ERR_ARG, "negative length");
@@ -1318,12 +1318,15 @@ int vtc_prepare_audio(vtc_model* m, const void* pcm, int32_t format, int64_t n_i
   hipStream_t s = (hipStream_t)stream;
   const long long blocks = (need + 255) / 256;
   if (blocks > 0x7fffffffLL) return fail(m, VTC_ERR_ARG, "input too long");
-  const double bytes = (double)n_in * n_channels * (format == 0 ? 2 : 4) + (double)need * 4;
+  const double bytes = (double)n_in * n_channels * (format == 0 ? 2 : format == 1 ? 4 : 3) + (double)need * 4;
   if (format == 0)
-    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
+    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
+                                                         (long long)n_in, n_channels, t, out, (long long)need));
+  else if (format == 1)
+    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
                                                          (long long)n_in, n_channels, t, out, (long long)need));
   else
-    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
+    LAUNCH(m, PC_OTHER, 0.0, bytes, s, hipLaunchKernelGGL((prepare_audio_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, pcm,
                                                          (long long)n_in, n_channels, t, out, (long long)need));
   HIP_TRY(m, hipGetLastError());
   return VTC_OK;

@@ -285,13 +285,17 @@ class VtcEngine:
     # ------------------------------------------------------------------ audio front-end
     def prepare_audio(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:
         """Interleaved PCM on the device, int16 or float32, shape (n,) or (n, channels) -> mono float32 at 16 kHz
-        (include/vtc_amd.h: vtc_prepare_audio).  Runs on the current stream."""
-        if pcm.device != self.device or not pcm.is_contiguous() or pcm.dim() not in (1, 2):
+        (include/vtc_amd.h: vtc_prepare_audio).  Packed 24-bit PCM is a uint8 tensor of shape (n, channels, 3), the bytes
+        as a WAV file stores them.  Runs on the current stream."""
+        if pcm.dtype == torch.uint8:
+            if pcm.device != self.device or not pcm.is_contiguous() or pcm.dim() != 3 or pcm.shape[2] != 3:
+                raise ValueError("packed 24-bit pcm must be a contiguous uint8 (n, channels, 3) tensor on the engine's device")
+        elif pcm.device != self.device or not pcm.is_contiguous() or pcm.dim() not in (1, 2):
             raise ValueError("pcm must be a contiguous (n,) or (n, channels) tensor on the engine's device")
-        if pcm.dtype not in (torch.int16, torch.float32):
-            raise ValueError(f"pcm dtype must be int16 or float32, got {pcm.dtype}")
+        if pcm.dtype not in (torch.int16, torch.float32, torch.uint8):
+            raise ValueError(f"pcm dtype must be int16, float32 or uint8 (packed int24), got {pcm.dtype}")
         n = int(pcm.shape[0])
-        ch = int(pcm.shape[1]) if pcm.dim() == 2 else 1
+        ch = int(pcm.shape[1]) if pcm.dim() >= 2 else 1
         if ch == 1 and pcm.dtype == torch.float32 and int(sample_rate) == SAMPLE_RATE:
             return pcm.reshape(-1)                      # already what the model consumes
         n_out = int(self._lib.vtc_resampled_length(n, int(sample_rate)))
@@ -299,7 +303,8 @@ class VtcEngine:
             raise ValueError(f"bad length / sample rate ({n}, {sample_rate})")
         out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)
         got = C.c_int64(0)
-        L.check(self._lib.vtc_prepare_audio(self._handle, C.c_void_p(pcm.data_ptr()), 0 if pcm.dtype == torch.int16 else 1, n,
+        fmt = 0 if pcm.dtype == torch.int16 else 1 if pcm.dtype == torch.float32 else 2
+        L.check(self._lib.vtc_prepare_audio(self._handle, C.c_void_p(pcm.data_ptr()), fmt, n,
                                             ch, int(sample_rate), C.c_void_p(out.data_ptr()), n_out, C.byref(got),
                                             self._stream()), self._handle)
         return out[: got.value]

@@ -141,7 +141,7 @@ def stage_audio(path, engine) -> torch.Tensor:
         if bufs is None:
             bufs = _TLS.chunk_bufs = [torch.empty(STAGE_CHUNK_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
         flat = pcm.reshape(-1)
-        tdt = torch.int16 if pcm.dtype == np.int16 else torch.float32
+        tdt = _TORCH_PCM[pcm.dtype.type]
         per = STAGE_CHUNK_BYTES // flat.dtype.itemsize
         done = [None, None]
         with torch.cuda.stream(copy_stream):
@@ -158,7 +158,7 @@ def stage_audio(path, engine) -> torch.Tensor:
             wav = engine.prepare_audio(dev.view(pcm.shape), sr)
     else:
         if isinstance(pcm, np.memmap) or pcm.nbytes >= (8 << 20) or not pcm.flags.writeable:
-            host = torch.empty(pcm.shape, dtype=torch.int16 if pcm.dtype == np.int16 else torch.float32, pin_memory=True)
+            host = torch.empty(pcm.shape, dtype=_TORCH_PCM[pcm.dtype.type], pin_memory=True)
             np.copyto(host.numpy(), pcm)                  # page cache / mmap -> pinned staging, no conversion on the host
         else:
             host = torch.from_numpy(pcm)                  # small file, already in memory: a pageable copy is cheaper than pinning
@@ -174,6 +174,7 @@ def stage_audio(path, engine) -> torch.Tensor:
     return wav
 
 
+_TORCH_PCM = {np.int16: torch.int16, np.float32: torch.float32, np.uint8: torch.uint8}   # uint8 = packed 24-bit PCM (n, ch, 3)
 STAGE_CHUNK_BYTES = 64 << 20       # long recordings cross PCIe in pieces of this size (two pinned buffers per reader thread)
 BUNDLE_FILE_BYTES = 4 << 20        # files up to this size (~2 min of 16 kHz PCM16) are staged in bundles
 BUNDLE_BYTES = 16 << 20            # pinned staging buffer of a reader thread (int16 samples of one bundle)
