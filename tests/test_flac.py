@@ -180,6 +180,10 @@ def test_aiff_against_the_standard_library_writer(tmp_path):
         got, sr = read_pcm(path)
         want = x.astype(np.int16) if width == 2 else (x / float(1 << (bits - 1))).astype(np.float32)
         want = want[:, 0] if nch == 1 else want
+        if width == 3:      # packed little-endian bytes for the GPU front-end; the host route unpacks them exactly
+            from vtc_amd.audio import pcm24_to_float32
+            assert got.dtype == np.uint8 and got.shape == (4000, nch, 3)
+            got = pcm24_to_float32(got)
         assert sr == rate and got.dtype == want.dtype and np.array_equal(got, want), (width, nch)
     # AIFF-C little-endian PCM ('sowt'), written by hand
     x = rng.integers(-32768, 32768, size=(1000, 2), dtype=np.int64).astype(np.int16)

@@ -290,11 +290,10 @@ def decode_aiff(data):
         elif width == 4:
             x = (raw.view(order + "i4").astype(np.float64) / 2147483648.0).astype(np.float32)
         elif width == 3:
-            b = raw.reshape(-1, 3).astype(np.int32)
-            hi, mid, lo = (b[:, 0], b[:, 1], b[:, 2]) if order == ">" else (b[:, 2], b[:, 1], b[:, 0])
-            v = (hi << 16) | (mid << 8) | lo
-            v = np.where(v >= (1 << 23), v - (1 << 24), v)
-            x = (v.astype(np.float64) / float(1 << 23)).astype(np.float32)
+            # packed 24-bit: handed on as little-endian bytes, uint8 (n, channels, 3), which the GPU front-end unpacks
+            # (vtc_prepare_audio format 2; read_audio: pcm24_to_float32); big-endian files cost one byte-reversing copy
+            p = raw.reshape(n, ch, 3)
+            return (p if order == "<" else np.ascontiguousarray(p[..., ::-1])), rate
         else:
             raise ValueError(f"AIFF: unsupported sample size {bits}")
     else:
