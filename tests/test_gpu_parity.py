@@ -681,7 +681,14 @@ def test_cli_24_bit_wav_files_cross_pcie_packed(weights, tmp_path, monkeypatch):
     up = np.interp(np.arange(int(9.1 * 48000)) / 48000.0, np.arange(len(x)) / 16000.0, x)
     st = np.clip(np.round(np.stack([up, 0.5 * up], axis=1) * 8388608.0), -8388608, 8388607).astype(np.int32)
     wav24(tmp_path / "audio" / "s24.wav", st, 48000)
-    (tmp_path / "manifests" / "w24.csv").write_text(f"path\n{tmp_path / 'audio' / 'm24.wav'}\n{tmp_path / 'audio' / 's24.wav'}\n")
+    import aifc
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with aifc.open(str(tmp_path / "audio" / "a24.aiff"), "wb") as f:      # the mono samples again, big-endian in an AIFF
+            f.setnchannels(1); f.setsampwidth(3); f.setframerate(16000)
+            f.writeframes(mono[:, 0].astype(">i4").view(np.uint8).reshape(-1, 4)[:, 1:].tobytes())
+    (tmp_path / "manifests" / "w24.csv").write_text("path\n" + "".join(f"{tmp_path / 'audio' / n}\n" for n in ("m24.wav", "s24.wav", "a24.aiff")))
     (tmp_path / "cfg.yml").write_text("model:\n  name: surgical_hydra\naudio:\n  chunk_duration_s: 4.0\n")
     got, _ = audio.read_pcm(tmp_path / "audio" / "s24.wav")
     assert got.dtype == np.uint8 and got.shape == (len(st), 2, 3)
@@ -689,7 +696,9 @@ def test_cli_24_bit_wav_files_cross_pcie_packed(weights, tmp_path, monkeypatch):
     out = tmp_path / "output" / "w24"
     seg = pq.read_table(out / "vtc_raw" / "shard_0.parquet").to_pylist()
     meta = pq.read_table(out / "vtc_meta" / "shard_0.parquet").to_pylist()
-    assert [r["uid"] for r in meta] == ["m24", "s24"] and all(r["error"] == "" for r in meta)
+    assert [r["uid"] for r in meta] == ["m24", "s24", "a24"] and all(r["error"] == "" for r in meta)
+    rows_of = lambda u: [(r["onset"], r["offset"], r["duration"], r["label"]) for r in seg if r["uid"] == u]
+    assert rows_of("a24") == rows_of("m24") and len(rows_of("a24")) > 3
     eng = _engine(weights, 4.0, 8)
     lo, hi = logit_bounds(THR, O.DEFAULT_LABELS)
     for uid in ("m24", "s24"):
