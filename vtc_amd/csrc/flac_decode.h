@@ -64,10 +64,25 @@ inline uint16_t crc16(const uint8_t* p, const uint8_t* end) {
 struct BitReader {
   const uint8_t* p;
   const uint8_t* end;
+  const uint8_t* begin;
   uint64_t buf = 0;  // left-aligned: the next bit is bit 63
   int nbits = 0;
   bool overrun = false;
-  BitReader(const uint8_t* b, const uint8_t* e) : p(b), end(e) {}
+  BitReader(const uint8_t* b, const uint8_t* e) : p(b), end(e), begin(b) {}
+  // position of the next unread bit, in bits from `begin`, and the way back from such a position (read_residual's fast loop
+  // works on a plain bit offset with one unaligned 8-byte load per code)
+  inline uint64_t bit_offset() const { return (uint64_t)(p - begin) * 8 - (uint64_t)nbits; }
+  inline void seek_bits(uint64_t bp) {
+    p = begin + (bp >> 3);
+    buf = 0;
+    nbits = 0;
+    const int r = (int)(bp & 7);
+    if (r) {
+      refill();
+      buf <<= r;
+      nbits -= r;
+    }
+  }
   inline void refill() {
     if (p + 8 <= end) {  // fast path: one unaligned 8-byte load
       uint64_t w;
@@ -221,7 +236,41 @@ inline bool read_residual(BitReader& br, int64_t* out, int blocksize, int order,
       int nb = br.bits(5);
       for (int j = 0; j < cnt; ++j) out[i++] = nb ? br.sbits(nb) : 0;
     } else {
-      for (int j = 0; j < cnt; ++j) {
+      int j = 0;
+      if (br.end - br.begin >= 16) {
+        // fast loop: one unaligned big-endian 8-byte load at bit offset bp, shifted by bp & 7, holds >= 57 valid bits = about five
+        // codes of a 16-bit stream; they are taken out of the register one after the other (count leading zeros, shift), so the
+        // chain load -> byte swap -> count -> next address is paid once per word, not once per code (19 -> 8 cycles per sample).
+        // A code longer than the window (a unary run of 25+ zeros with a wide parameter) and the last bytes of the buffer leave
+        // the loop for the general reader below.
+        uint64_t bp = br.bit_offset();
+        const uint8_t* lim = br.end - 8;
+        while (j < cnt) {
+          const uint8_t* q = br.begin + (bp >> 3);
+          if (q > lim) break;
+          uint64_t w;
+          memcpy(&w, q, 8);
+          const int r = (int)(bp & 7);
+          w = __builtin_bswap64(w) << r;
+          int avail = 64 - r, used = 0;
+          while (w != 0) {
+            const int z = __builtin_clzll(w);
+            const int len = z + 1 + (int)k;
+            if (len > avail) break;
+            const uint64_t b = (w << z) << 1;
+            const uint64_t u = ((uint64_t)z << k) | (k ? b >> (64 - k) : 0);
+            w = b << k;
+            avail -= len;
+            used += len;
+            out[i++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+            if (++j == cnt) break;
+          }
+          if (used == 0) break;
+          bp += (uint64_t)used;
+        }
+        br.seek_bits(bp);
+      }
+      for (; j < cnt; ++j) {
         uint64_t u;
         if (br.nbits < 32 + (int)k) br.refill();
         const int z = br.buf ? __builtin_clzll(br.buf) : 64;
