@@ -31,6 +31,9 @@ def main() -> None:
     ap.add_argument("--max_s", type=float, default=30.0)
     ap.add_argument("--chunk", type=float, default=4.0)
     ap.add_argument("--batch", type=int, default=164)
+    ap.add_argument("--format", default="wav", choices=["wav", "flac"], help="clip members: wav, or flac as the reference's packer "
+                    "writes them (src/packaging/writer.py:36; 24 distinct clips encoded by the test encoder and reused)")
+    ap.add_argument("--skip_per_clip", action="store_true")
     args = ap.parse_args()
     from scipy.io import wavfile
 
@@ -43,16 +46,27 @@ def main() -> None:
         (root / "output" / name / "shards").mkdir(parents=True)
     per_tar = 500
     durs = rng.uniform(args.min_s, args.max_s, args.clips)
+    flacs = []
+    if args.format == "flac":
+        from oracle import flac_codec           # a dev tool may use the test encoder to make inputs; the product never does
+        for d in np.linspace(args.min_s, args.max_s, 24):
+            n = int(d * 16000)
+            o = int(rng.integers(0, len(pcm) - n))
+            flacs.append((n, flac_codec.encode(pcm[o:o + n].astype(np.int64), 16000, subframe="lpc")))
+        print(f"{len(flacs)} distinct FLAC clips encoded", flush=True)
     for t in range(0, args.clips, per_tar):
         path = root / "output" / "batched" / "shards" / f"shards-{t // per_tar:04d}.tar"
         with tarfile.open(path, "w") as tf:
             for c in range(t, min(t + per_tar, args.clips)):
-                n = int(durs[c] * 16000)
-                o = int(rng.integers(0, len(pcm) - n))
-                buf = io.BytesIO()
-                wavfile.write(buf, 16000, pcm[o:o + n])
-                data = buf.getvalue()
-                info = tarfile.TarInfo(f"rec_{c:06d}.wav")
+                if flacs:
+                    n, data = flacs[int(rng.integers(len(flacs)))]
+                else:
+                    n = int(durs[c] * 16000)
+                    o = int(rng.integers(0, len(pcm) - n))
+                    buf = io.BytesIO()
+                    wavfile.write(buf, 16000, pcm[o:o + n])
+                    data = buf.getvalue()
+                info = tarfile.TarInfo(f"rec_{c:06d}.{args.format}")
                 info.size = len(data)
                 tf.addfile(info, io.BytesIO(data))
                 total_s += n / 16000.0
@@ -65,7 +79,10 @@ def main() -> None:
     from vtc_amd.analysis import vtc_on_clips as clips
     import torch
     out = {"clips": args.clips, "audio_hours": total_s / 3600.0, "chunk_duration_s": args.chunk, "batch": args.batch}
+    out["format"] = args.format
     for name, per_clip in (("batched", False), ("per_clip", True)):
+        if per_clip and args.skip_per_clip:
+            continue
         t0 = time.time()
         clips.main(name, config=str(root / "cfg.yml"), checkpoint="synthetic:0", batch_size=args.batch, per_clip=per_clip)
         torch.cuda.synchronize()

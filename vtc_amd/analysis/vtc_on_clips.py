@@ -27,8 +27,10 @@ import queue
 import sys
 import tarfile
 import threading
+import os
 import time
 from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -307,37 +309,52 @@ def main(dataset: str, config: str = "VTC-2.0/model/config.yml", checkpoint: str
             copy_stream.synchronize()
             return wav
 
+        def handle(clip_id, fut):
+            """One clip, in tar order: a resumed clip (fut None), or its decoded PCM (or the decoder's exception)."""
+            nonlocal pos, windows
+            if fut is None:
+                emit()
+                todo.put((clip_id, None, None))
+                return
+            try:
+                pcm, sr = fut.result()
+                plain = (not per_clip and pcm.dtype == np.int16 and pcm.ndim == 1 and sr == 16000
+                         and RF_SIZE <= pcm.shape[0] <= bundle_cap)
+                if plain:
+                    n = int(pcm.shape[0])
+                    n_win = -(-(n - RF_SIZE + 1) // step)
+                    if pos + n > bundle_cap or (bundle and windows + n_win > batch_size):
+                        emit()
+                    host_np[pos:pos + n] = pcm
+                    bundle.append((clip_id, pos, n))
+                    pos += n
+                    windows += n_win
+                    if windows >= batch_size:
+                        emit()
+                else:
+                    emit()
+                    todo.put((clip_id, stage_one(pcm, sr), None))
+            except Exception as e:
+                emit()
+                todo.put((clip_id, None, e))
+
+        # The members are decoded on a small pool (the packer writes FLAC by default, src/packaging/writer.py:36; the library's
+        # decoder runs outside the GIL at ~2 audio-hours/s per thread, an eighth of what the GPU takes): this thread walks the
+        # tar, submits the decodes and consumes them in tar order, a bounded number of clips ahead.
+        n_dec = max(1, int(os.environ.get("VTC_CLIP_DECODERS", str(max(1, min(8, len(os.sched_getaffinity(0)) - 2))))))
+        ahead: deque = deque()
         try:
-            for tar_path in tar_files:
-                for sample in iter_tar_samples(tar_path):
-                    if stop.is_set():
-                        return
-                    clip_id = sample["__key__"]
-                    if clip_id in completed:
-                        emit()
-                        todo.put((clip_id, None, None))
-                        continue
-                    try:
-                        pcm, sr = decode_clip(sample)
-                        plain = (not per_clip and pcm.dtype == np.int16 and pcm.ndim == 1 and sr == 16000
-                                 and RF_SIZE <= pcm.shape[0] <= bundle_cap)
-                        if plain:
-                            n = int(pcm.shape[0])
-                            n_win = -(-(n - RF_SIZE + 1) // step)
-                            if pos + n > bundle_cap or (bundle and windows + n_win > batch_size):
-                                emit()
-                            host_np[pos:pos + n] = pcm
-                            bundle.append((clip_id, pos, n))
-                            pos += n
-                            windows += n_win
-                            if windows >= batch_size:
-                                emit()
-                        else:
-                            emit()
-                            todo.put((clip_id, stage_one(pcm, sr), None))
-                    except Exception as e:
-                        emit()
-                        todo.put((clip_id, None, e))
+            with ThreadPoolExecutor(max_workers=n_dec, thread_name_prefix="clip-decode") as pool:
+                for tar_path in tar_files:
+                    for sample in iter_tar_samples(tar_path):
+                        if stop.is_set():
+                            return
+                        clip_id = sample["__key__"]
+                        ahead.append((clip_id, None if clip_id in completed else pool.submit(decode_clip, sample)))
+                        while len(ahead) > 4 * n_dec:
+                            handle(*ahead.popleft())
+                while ahead and not stop.is_set():
+                    handle(*ahead.popleft())
             emit()
         except BaseException as e:          # a broken tar must not leave the consumer waiting
             todo.put((None, None, e))
